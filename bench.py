@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the fused RIS-VEC step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one launch of the fused north-star kernel (RIS cascaded gains + step(),
+`risvec_step_fused`) over the whole resident env batch: every env advances by one
+`Environ.step()` with its channel gains recomputed from h_r and theta ("everything
+every step" mode of SURVEY 8d).  Workload at N=1: BASELINE.json configs[2]
+(32 768 envs x 8 vehicles x 64 RIS elements, fp32/complex64, synthetic channel draws);
+N>1: the same per GPU (weak scaling), env ids sharded by rank, plus the joint-observation
+all-gather for the global critic on a side stream.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and
+`cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(V: int, M: int) -> int:
+    """bytes one env-step must move in fused mode (fp32 / complex64):
+    reads h_r 8VM + theta 8M + action 8V + DataBuf 4V + path-loss 4V + partner 4V + n_groups 4
+    + Q 4; writes gain 4V + DataBuf 4V + reward 4V + rate/data_t/data_p 12V + obs 20V + Q 4 +
+    metrics 56."""
+    return 8 * V * M + 8 * M + 64 * V + 68
+
+
+def synthetic_groups(E: int, V: int, rng) -> tuple:
+    """V//4 random pairs + singles per env (SURVEY 8d 'synthetic inputs')."""
+    partner = np.full((E, V), -1, dtype=np.int32)
+    perm = np.argsort(rng.random((E, V)), axis=1).astype(np.int32)
+    rows = np.arange(E)
+    for k in range(V // 4):
+        a, b = perm[:, 2 * k], perm[:, 2 * k + 1]
+        partner[rows, a] = b
+        partner[rows, b] = a + (1 << 16)
+    n_groups = np.full(E, V - V // 4, dtype=np.int32)
+    return partner, n_groups
+
+
+def build_env(E: int, V: int, M: int, device, seed: int, env_offset: int):
+    from ris_vec_marl_amd import VecEnviron, reference_lanes, apply_yaml_config
+    L = reference_lanes()
+    env = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3,
+                     n_envs=E, device=device, seed=seed, env_offset=env_offset)
+    # YAML-effective physics: shipped config.yaml + driver Config defaults
+    apply_yaml_config(env, dict(mec=dict(f_local_max=3.0e9, cycles_per_bit=300), phy=dict(bandwidth_MHz=5, P_max=2.0),
+                                env=dict(rate=1), reward=dict(sample=False, w_d_fixed=1.0, w_e_fixed=1.0),
+                                qos_enable=True, qos_penalty=1.5))
+    env.make_new_game()                 # reference reset distribution (Philox)
+    for _ in range(3):
+        env.renew_positions()
+    env.compute_parms()                 # h_r = reference steering vectors from geometry
+    env.Random_phase()                  # theta uniform over the 2^b discrete phases
+    return env
+
+
+def cpu_baseline(V: int, M: int, budget_s: float = 12.0) -> dict:
+    """The CPU oracle (float64 NumPy restatement of the reference) timed on this box's host
+    cores for the same per-step work (cascaded gains + step): baseline only."""
+    from oracle import risvec_oracle as orc
+    try:
+        torch.set_num_threads(1)
+    except Exception:
+        pass
+    rng = np.random.default_rng(0)
+    p = orc.OracleParams.yaml_effective()
+    b = orc.phase_R(M)
+
+    def make(Es):
+        pos = np.stack([rng.uniform(0, 400, (Es, V)), rng.uniform(0, 400, (Es, V))], -1)
+        dist, _, h_r = orc.geometry(pos, M)
+        th = np.exp(1j * orc.possible_angles(3)[rng.integers(0, 8, (Es, M))])
+        act = rng.uniform(0, 1, (Es, 2, V))
+        partner, ng = synthetic_groups(Es, V, rng)
+        return dict(dist=dist, h_r=h_r, th=th, act=act, partner=partner.astype(np.int64), ng=ng.astype(np.int64),
+                    buf=np.full((Es, V), 3.0), q=np.zeros(Es))
+
+    def run(st, n_iter):
+        t0 = time.perf_counter()
+        for _ in range(n_iter):
+            gain = orc.gain_free(st["th"], st["h_r"], b, st["dist"])
+            arr = rng.poisson(p.rate, st["buf"].shape)
+            o = orc.step(st["buf"], st["q"], gain, st["act"], st["partner"], st["ng"], arr, p)
+            st["buf"], st["q"] = o["data_buf"], o["mec_q"]
+        return time.perf_counter() - t0
+
+    # (a) vectorised over a 2048-env sample (the strongest form of the port)
+    Es = 2048
+    st = make(Es)
+    run(st, 1)
+    t1 = run(st, 2) / 2
+    n = max(2, int(0.6 * budget_s / t1))
+    tv = run(st, n) / n
+    # (b) one env at a time, as the reference itself is driven
+    s1 = make(1)
+    run(s1, 5)
+    t1e = run(s1, 20) / 20
+    n1 = max(20, int(0.3 * budget_s / t1e))
+    ts = run(s1, n1) / n1
+    return dict(value=Es / tv, unit="env-steps/s", cores=1, kind="port",
+                sample="oracle/risvec_oracle.py (float64 NumPy, 1 thread): gain_free+step vectorised over %d envs "
+                       "x %d steps at V=%d, M=%d; single-env stepping (how the reference is driven) = %.0f env-steps/s"
+                       % (Es, n, V, M, 1.0 / ts),
+                single_env_value=1.0 / ts, host_cores=os.cpu_count())
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs-per-gpu", type=int, default=32768)
+    ap.add_argument("--veh", type=int, default=8)
+    ap.add_argument("--ris", type=int, default=64)
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N>1: all-gather the joint observation every k steps (0 = never)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="fused", choices=["fused", "cached", "bcd"],
+                    help="fused: gains+step each step (headline); cached: step only (reference cadence); "
+                         "bcd: BCD sweep + gains + step each step (BASELINE config 5)")
+    args = ap.parse_args()
+
+    from ris_vec_marl_amd import dist as rdist
+    rank, world, local = rdist.init_from_env()
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    E, V, M = args.envs_per_gpu, args.veh, args.ris
+    start, _ = rdist.shard_range(E * world, rank, world)
+    env = build_env(E, V, M, device, seed=0, env_offset=start)
+    rng = np.random.default_rng(1234 + rank)
+    action = torch.from_numpy(rng.uniform(0, 1, (E, 2, V)).astype(np.float32)).to(device)
+    partner_np, ng_np = synthetic_groups(E, V, rng)
+    partner = torch.from_numpy(partner_np).to(device)
+    n_groups = torch.from_numpy(ng_np).to(device)
+    if args.mode == "cached":
+        env.update_channel_gains()
+
+    gather = None
+    gather_note = "n/a (1 GPU)"
+    if world > 1 and args.gather_every > 0:
+        try:
+            gather = rdist.JointObsGather(E, V, device)
+            gather.start(env.tensors["obs"]); gather.wait()
+            gather_note = "joint obs [E_local,5V] fp32 all-gather (RCCL) every %d step(s), side stream, double-buffered" % args.gather_every
+        except Exception as ex:           # keep the env path measurable even if RCCL is unavailable
+            gather = None
+            gather_note = "disabled: %r" % (ex,)
+
+    fused, bcd = args.mode != "cached", args.mode == "bcd"
+
+    def one_step(i: int) -> None:
+        env.step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=True, power_w=False, obs=True)
+        if gather is not None and i % args.gather_every == 0:
+            gather.wait()
+            gather.start(env.tensors["obs"])
+
+    for i in range(args.warmup):
+        one_step(i)
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        one_step(i)
+    ev1.record()
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        torch.distributed.barrier()
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    # average device time per launch on the launch stream (events bracket the K launches,
+    # so inter-launch gaps are included: slightly pessimistic)
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+
+    if rank != 0:
+        return
+    per_env = {"fused": algorithmic_bytes(V, M), "cached": 60 * V + 68,
+               "bcd": 8 * V * M + 16 * M + 64 * V + 68}[args.mode]
+    bytes_per_launch = per_env * E
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/sec (all agents) at 8 veh x 64 RIS",
+        "value": E * world * args.steps / dt,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %d parallel envs/GPU x %d vehicles x %d RIS elements, fp32/complex64, "
+                               "%s every step, metrics+obs written, Philox arrivals" % (E, V, M,
+                               {"fused": "RIS cascaded gains + step()", "cached": "step() on cached gains",
+                                "bcd": "BCD sweep + gains + step()"}[args.mode]),
+                   "envs_per_gpu": E, "n_veh": V, "n_ris": M, "mode": args.mode, "allgather": gather_note,
+                   "agent_steps_per_s": E * world * args.steps / dt * V},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": {"fused": "k_step_fused", "cached": "k_step", "bcd": "k_bcd+k_step_fused"}[args.mode],
+                     "algorithmic_bytes_per_env_step": per_env, "bytes_per_launch": bytes_per_launch,
+                     "avg_launch_ms": kernel_ms},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(V, M)
+    elif world > 1:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

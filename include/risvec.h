@@ -1,0 +1,239 @@
+/* risvec.h -- C ABI of the MI355X-native vectorised RIS-VEC environment.
+ *
+ * This is the drop-in boundary for ONE hot path of 20242204033/RIS-VEC-MARL:
+ * `Simulation-MARL-BCD/Environment.py` (ENV below) -- class `Environ`, its reset /
+ * mobility / geometry / channel-gain / BCD / step() methods.  The reference has no
+ * FFI of its own (the boundary there is a Python class, ENV:56); every entry point
+ * below names the reference method it replaces, batched over `n_envs` independent
+ * environments.  The Python host side (`ris_vec_marl_amd/`) binds these with ctypes;
+ * `INTEGRATION.md` shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Plain C: device pointers, sizes, POD structs.  No torch / HIP types: a stream
+ *     is passed as `void*` (a `hipStream_t`; NULL = the default stream).
+ *   - All launches are asynchronous on `stream`.  Return value: RISVEC_OK or an
+ *     error code; `risvec_last_error()` gives the message (thread-local).
+ *   - Arrays are row-major, E = n_envs, V = n_veh, M = n_ris.  Complex arrays are
+ *     interleaved (re, im) float pairs.  Every pointer must be 16-byte aligned.
+ *   - Random draws: each entry point takes optional "injected draw" arrays (used by
+ *     the parity tests, which replay the reference's own MT19937 draws); when NULL
+ *     the kernel draws from Philox4x32-10 keyed by (seed; global env id, vehicle,
+ *     counter, site), so results do not depend on how envs are sharded over GPUs.
+ */
+#ifndef RISVEC_H
+#define RISVEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RISVEC_ABI_VERSION 3
+#define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
+#define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
+#define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
+#define RISVEC_METRICS 16         /* floats per env in `metrics` (14 used)       */
+#define RISVEC_PARTNER_SINGLE (-1)      /* alone in a 1-element NOMA group (OMA)     */
+#define RISVEC_PARTNER_NONE (-2)        /* in no group / a group of another size     */
+#define RISVEC_PARTNER_SECOND (1 << 16) /* added to the index when listed 2nd in pair */
+
+enum {
+    RISVEC_OK = 0,
+    RISVEC_ERR_ARG = 1,         /* NULL / misaligned pointer, bad struct version    */
+    RISVEC_ERR_SHAPE = 2,       /* dimension outside what the kernels support       */
+    RISVEC_ERR_LAUNCH = 3,      /* HIP reported a launch error                      */
+    RISVEC_ERR_UNSUPPORTED = 4
+};
+
+enum { RISVEC_DIR_U = 0, RISVEC_DIR_D = 1, RISVEC_DIR_L = 2, RISVEC_DIR_R = 3 };
+
+/* ENV:70, 263, 311-317 */
+enum { RISVEC_CH_FREE = 0, RISVEC_CH_3GPP_UMI = 1, RISVEC_CH_3GPP_UMA = 2, RISVEC_CH_OTHER = 3 };
+
+/* step flags */
+enum {
+    RISVEC_STEP_METRICS = 1,        /* write metrics[E,16] (the 13 last_* + global_reward) */
+    RISVEC_STEP_POWER_W = 2,        /* write power_w[E,2,V]  (last_power_W, ENV:664-666)   */
+    RISVEC_STEP_POLICY_ACTION = 4,  /* `action` is the policy output [E,V,2] in [-1,1]; apply
+                                       marl_train_bcd.py:1601-1608 in-kernel             */
+    RISVEC_STEP_OBS = 8             /* write obs[E,V,5] (marl_train_bcd.py:819-827)        */
+};
+
+/* Physics / geometry parameters: the attributes of `Environ` that the driver sets
+ * (ENV:57-190, overridden by marl_train_bcd.py:548-779).  Passed by value to kernels. */
+typedef struct RisVecParams {
+    uint32_t abi_version;       /* = RISVEC_ABI_VERSION                               */
+    uint32_t struct_bytes;      /* = sizeof(RisVecParams)                             */
+    /* PHY  (ENV:72-77, 125, 555) */
+    float bandwidth_mhz;
+    float noise_power;
+    float p_max;
+    float power_scale;
+    /* QoS  (ENV:79-82) */
+    int32_t qos_enable;
+    float r_min_bpshz;
+    float d_max_s;
+    float qos_penalty;
+    /* timing / compute  (ENV:101-116) */
+    float time_fast;
+    float k_cpu;
+    float f_local_max;
+    float f_edge_max;
+    float cycles_per_bit;
+    float cpu_share_floor;      /* raw attribute; the kernels apply ENV:574-577       */
+    /* reward  (ENV:138-143, 696-703) */
+    float w_d;
+    float w_e;
+    float reward_clip;
+    /* arrivals  (ENV:156, 717-719): rate + its CDF table, built on the host in f64    */
+    float arrival_rate;
+    float poisson_cdf[RISVEC_POISSON_TABLE];
+    /* 3GPP modes  (ENV:186-189, 96) */
+    float fc_ghz;
+    float shadow_std_los;
+    float shadow_std_nlos;
+    float rician_k_db;
+    float veh_ant_gain;
+    int32_t n_lanes;            /* entries used in each lane array (reference: 4)     */
+    /* geometry, double: positions are advanced in f64 exactly like the reference     */
+    double time_slow;           /* ENV:101 */
+    double width, height;       /* ENV:63-64 */
+    double lanes_up[RISVEC_MAX_LANES];
+    double lanes_down[RISVEC_MAX_LANES];
+    double lanes_left[RISVEC_MAX_LANES];
+    double lanes_right[RISVEC_MAX_LANES];
+} RisVecParams;
+
+/* Device-resident state and outputs of E environments (struct-of-arrays).
+ * The struct itself lives in HOST memory; the pointers are device pointers. */
+typedef struct RisVecState {
+    uint32_t abi_version;
+    uint32_t struct_bytes;
+    int32_t n_envs, n_veh, n_ris, control_bit;
+    int64_t env_offset;     /* global id of local env 0 (multi-GPU sharding; RNG key) */
+    /* vehicles (ENV:45-53) */
+    double *pos;            /* [E,V,2] f64  x,y                                       */
+    int32_t *dir;           /* [E,V]   RISVEC_DIR_*                                   */
+    float *vel;             /* [E,V]   m/s (integers)                                 */
+    /* geometry (ENV:241-253) */
+    float *dist_r;          /* [E,V]   distances_R_i                                  */
+    float *ang_r;           /* [E,V]   angles_R_i                                     */
+    float *pl;              /* [E,V]   ro^2 / (d_Rv^2.2 d_BR^2.5)   (ENV:270-272)     */
+    float *h_r;             /* [E,V,M] c64  phases_R_i                                */
+    /* RIS (ENV:171-179) */
+    float *theta;           /* [E,M]   c64  elements_phase_shift_complex              */
+    const float *b;         /* [M]     c64  phase_R (shared by all envs)              */
+    const float *h_d;       /* [E,V]   c64  optional direct link (NULL = 0, as ref.)  */
+    float *gain;            /* [E,V]   channel_gains                                  */
+    /* queues (ENV:116, 151) */
+    float *data_buf;        /* [E,V]   DataBuf, kbit                                  */
+    float *mec_q;           /* [E]     mec_queue_cycles                               */
+    /* step outputs (ENV:731 + attributes read by the driver) */
+    float *rate;            /* [E,V]   vehicle_rate                                   */
+    float *data_t;          /* [E,V]                                                  */
+    float *data_p;          /* [E,V]                                                  */
+    float *reward;          /* [E,V]   per_user_reward                                */
+    float *over_power;      /* [E,V]                                                  */
+    float *obs;             /* [E,V,5] marl_get_state                                 */
+    float *metrics;         /* [E,16]  see RISVEC_METRIC_* (slots 14,15 reserved = 0) */
+    float *power_w;         /* [E,2,V] last_power_W (may be NULL unless flag set)     */
+} RisVecState;
+
+/* metrics slots (ENV line in comment) */
+enum {
+    RISVEC_METRIC_GLOBAL_REWARD = 0,   /* 721 */
+    RISVEC_METRIC_OFF_KBIT_SUM = 1,    /* 612 */
+    RISVEC_METRIC_LOCAL_KBIT_SUM = 2,  /* 613 */
+    RISVEC_METRIC_MEC_QUEUE = 3,       /* 614 */
+    RISVEC_METRIC_BACKLOG_MEAN = 4,    /* 649 */
+    RISVEC_METRIC_DELAY_LOCAL = 5,     /* 643 */
+    RISVEC_METRIC_DELAY_EDGE_Q = 6,    /* 644 */
+    RISVEC_METRIC_DELAY_EDGE_C = 7,    /* 645 */
+    RISVEC_METRIC_T_TX = 8,            /* 646 */
+    RISVEC_METRIC_MEC_UTIL = 9,        /* 653 */
+    RISVEC_METRIC_LOCAL_UTIL = 10,     /* 656 */
+    RISVEC_METRIC_QOS_VIOL = 11,       /* 677 */
+    RISVEC_METRIC_DELAY = 12,          /* 710 */
+    RISVEC_METRIC_ENERGY = 13          /* 711 */
+};
+
+typedef void *risvec_stream_t;
+
+uint32_t risvec_abi_version(void);
+const char *risvec_last_error(void);
+
+/* Fill `p` with the class defaults of ENV:57-190 and the reference driver's lanes
+ * (marl_train_bcd.py:446-449).  Host-only helper. */
+void risvec_default_params(RisVecParams *p);
+
+/* make_new_game (ENV:733-737) + add_new_vehicles_by_number (ENV:381-410).
+ * spawn_ints [E,V,3] int32 = (aux, coord, velocity), buf0 [E] int32 (the single
+ * randint(5,9) of ENV:737); both NULL -> Philox.  Writes pos, dir, vel, data_buf.
+ * Like the reference it does NOT touch mec_q, theta, gain. */
+int risvec_reset(const RisVecState *s, const RisVecParams *p, const int32_t *spawn_ints,
+                 const int32_t *buf0, uint64_t seed, uint32_t counter, risvec_stream_t stream);
+
+/* renew_positions (ENV:412-542).  u_turn [E,V,8] float32 uniform draws consumed left
+ * to right, one per detected lane crossing; NULL -> Philox.  n_used [E,V] int32
+ * (optional) receives the number of draws consumed. */
+int risvec_mobility(const RisVecState *s, const RisVecParams *p, const float *u_turn,
+                    int32_t *n_used, uint64_t seed, uint32_t counter, risvec_stream_t stream);
+
+/* compute_parms (ENV:241-253): pos -> dist_r, ang_r, pl, h_r. */
+int risvec_geometry(const RisVecState *s, const RisVecParams *p, risvec_stream_t stream);
+
+/* update_channel_gains, "free" model (ENV:263-273): theta, h_r, b, pl -> gain. */
+int risvec_gain(const RisVecState *s, const RisVecParams *p, risvec_stream_t stream);
+
+/* update_channel_gains, 3GPP modes (ENV:275-327).  model = RISVEC_CH_*.  Injected
+ * draws (all [E,V] float32, all or none): u_los ~ U[0,1), z_shadow ~ N(0,1),
+ * small = small-scale power (ENV:13-25).  NULL -> Philox (Rayleigh or Rice per
+ * p->rician_k_db). */
+int risvec_gain_3gpp(const RisVecState *s, const RisVecParams *p, int32_t model,
+                     const float *u_los, const float *z_shadow, const float *small,
+                     uint64_t seed, uint32_t counter, risvec_stream_t stream);
+
+/* optimize_phase_shift (ENV:208-220) with the objective of ENV:222-231: one BCD sweep
+ * over theta in place.  idx_out [E,M] int32 (optional): chosen candidate, -1 = none. */
+int risvec_bcd(const RisVecState *s, const RisVecParams *p, int32_t *idx_out,
+               risvec_stream_t stream);
+
+/* get_next_phase (ENV:233-239): theta = exp(j*angle), angle [E,M] float32. */
+int risvec_set_phase(const RisVecState *s, const float *angle, risvec_stream_t stream);
+
+/* Random_phase (ENV:203-206): theta = exp(j*possible_angles[idx]); idx [E,M] int32 or
+ * NULL -> Philox. */
+int risvec_random_phase(const RisVecState *s, const int32_t *idx, uint64_t seed,
+                        uint32_t counter, risvec_stream_t stream);
+
+/* step (ENV:547-731) with compute_data_rate (ENV:331-372), using the cached `gain`.
+ * action [E,2,V] float32 (or [E,V,2] policy output with RISVEC_STEP_POLICY_ACTION),
+ * partner [E,V] int32 + n_groups [E] int32 encode `noma_groups`, arrivals [E,V] int32
+ * = the Poisson draws of ENV:718 (NULL -> Philox, counter = step index). */
+int risvec_step(const RisVecState *s, const RisVecParams *p, const float *action,
+                const int32_t *partner, const int32_t *n_groups, const int32_t *arrivals,
+                uint64_t seed, uint32_t counter, uint32_t flags, risvec_stream_t stream);
+
+/* compute_data_rate (ENV:331-372) on its own: p_off [E,V] float32 = offload power in W
+ * (row 0 of the reference's `power`), cached `gain` -> rate_out [E,V] bit/s/Hz. */
+int risvec_data_rate(const RisVecState *s, const RisVecParams *p, const float *p_off,
+                     const int32_t *partner, const int32_t *n_groups, float *rate_out,
+                     risvec_stream_t stream);
+
+/* The fused north-star kernel: update_channel_gains ("free") + step in ONE launch:
+ * one HBM pass over h_r and theta, gains exchanged in LDS, also written to `gain`. */
+int risvec_step_fused(const RisVecState *s, const RisVecParams *p, const float *action,
+                      const int32_t *partner, const int32_t *n_groups, const int32_t *arrivals,
+                      uint64_t seed, uint32_t counter, uint32_t flags, risvec_stream_t stream);
+
+/* BCD sweep + gains + step in one launch (BASELINE config 5: h_r read once into LDS). */
+int risvec_step_fused_bcd(const RisVecState *s, const RisVecParams *p, const float *action,
+                          const int32_t *partner, const int32_t *n_groups,
+                          const int32_t *arrivals, uint64_t seed, uint32_t counter,
+                          uint32_t flags, risvec_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RISVEC_H */

@@ -658,3 +658,66 @@ def randint_from_u32(x: np.ndarray, low: int, high: int) -> np.ndarray:
     """low + floor(x * (high-low) / 2^32)  (multiply-shift; no modulo bias loop)."""
     span = np.uint64(high - low)
     return (low + ((x.astype(np.uint64) * span) >> np.uint64(32))).astype(np.int64)
+
+
+def philox_reset(env_ids: np.ndarray, V: int, counter: int, seed: int, height: int = 400,
+                 n_lanes: int = 4) -> Tuple[np.ndarray, np.ndarray]:
+    """(spawn_ints [E,V,3], buf0 [E]) exactly as k_reset draws them."""
+    e = np.asarray(env_ids, dtype=np.uint64)[:, None]
+    v = np.arange(V, dtype=np.uint64)[None, :]
+    r0, r1, r2, r3 = philox4x32(e, v, np.uint64(counter), np.uint64(SITE_SPAWN), seed)
+    E = e.shape[0]
+    spawn = np.zeros((E, V, 3), dtype=np.int64)
+    lane = randint_from_u32(r0, 0, n_lanes)
+    n4 = 4 * (V // 4)
+    for vv in range(V):
+        if vv < n4:
+            slot = vv % 4
+            spawn[:, vv, 0] = lane[:, vv]
+            lo, hi = (220, 230) if slot in (0, 2) else (170, 180)
+            spawn[:, vv, 1] = randint_from_u32(r1[:, vv], lo, hi)
+            spawn[:, vv, 2] = randint_from_u32(r2[:, vv], 10, 15)
+        else:
+            spawn[:, vv, 0] = lane[:, vv] + 4 * randint_from_u32(r3[:, vv], 0, 4)
+            spawn[:, vv, 1] = randint_from_u32(r1[:, vv], 0, height)
+            spawn[:, vv, 2] = randint_from_u32(r2[:, vv], 15, 20)
+    b0, _, _, _ = philox4x32(e[:, 0], np.uint64(0), np.uint64(counter), np.uint64(SITE_BUF0), seed)
+    return spawn, randint_from_u32(b0, 5, 9)
+
+
+def philox_turn_draws(env_ids: np.ndarray, V: int, counter: int, seed: int) -> np.ndarray:
+    """u_turn [E,V,8] float32 exactly as k_mobility would consume them (block A then B)."""
+    e = np.asarray(env_ids, dtype=np.uint64)[:, None]
+    v = np.arange(V, dtype=np.uint64)[None, :]
+    a = philox4x32(e, v, np.uint64(counter), np.uint64(SITE_TURN_A), seed)
+    b = philox4x32(e, v, np.uint64(counter), np.uint64(SITE_TURN_B), seed)
+    return np.stack([u01(x) for x in a + b], axis=-1)
+
+
+def philox_phase_idx(env_ids: np.ndarray, M: int, counter: int, seed: int, control_bit: int) -> np.ndarray:
+    """idx [E,M] exactly as k_random_phase draws them."""
+    e = np.asarray(env_ids, dtype=np.uint64)[:, None]
+    m = np.arange(M, dtype=np.uint64)[None, :]
+    r0, _, _, _ = philox4x32(e, m, np.uint64(counter), np.uint64(SITE_PHASE), seed)
+    return randint_from_u32(r0, 0, 2 ** control_bit)
+
+
+def bcd_margin(theta, h_r, b, control_bit):
+    """For each (env, m) decision of a sweep: relative gap between the best and the
+    second-best candidate score (tests skip decisions with a tiny gap)."""
+    theta = np.array(theta, dtype=np.complex128, copy=True)
+    E, M = theta.shape
+    ang = possible_angles(control_bit)
+    cand = np.cos(ang) + 1j * np.sin(ang)
+    c = h_r.sum(axis=1) * b[None, :]
+    S = np.sum(theta * c, axis=1)
+    gap = np.zeros((E, M))
+    for m in range(M):
+        rest = S - theta[:, m] * c[:, m]
+        x = np.abs(rest[:, None] + cand[None, :] * c[:, m][:, None]) ** 2
+        xs = np.sort(x, axis=1)
+        gap[:, m] = (xs[:, -1] - xs[:, -2]) / np.maximum(xs[:, -1], 1e-300) if x.shape[1] > 1 else 1.0
+        k = np.argmax(x, axis=1)
+        theta[:, m] = np.where(xs[:, -1] > 0, cand[k], 0)
+        S = rest + theta[:, m] * c[:, m]
+    return gap

@@ -1,0 +1,143 @@
+"""ctypes binding of `csrc/librisvec.so` (the C ABI declared in `include/risvec.h`).
+
+The product path has no CPU fallback: if the shared library is missing this module
+raises at import of the symbol table, and every compute call goes through HIP.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+ABI_VERSION = 3
+POISSON_TABLE = 64
+MAX_LANES = 8
+MAX_VEH = 64
+METRICS = 16
+PARTNER_SINGLE = -1
+PARTNER_NONE = -2
+PARTNER_SECOND = 1 << 16
+
+OK, ERR_ARG, ERR_SHAPE, ERR_LAUNCH, ERR_UNSUPPORTED = range(5)
+DIR_U, DIR_D, DIR_L, DIR_R = range(4)
+CH_FREE, CH_3GPP_UMI, CH_3GPP_UMA, CH_OTHER = range(4)
+STEP_METRICS, STEP_POWER_W, STEP_POLICY_ACTION, STEP_OBS = 1, 2, 4, 8
+
+METRIC_NAMES = (
+    "global_reward", "last_off_kbit_sum", "last_local_kbit_sum", "last_mec_queue_cycles",
+    "last_backlog_kbit_mean", "last_delay_local_mean", "last_delay_edge_q_mean",
+    "last_delay_edge_c_mean", "last_t_tx_mean", "last_mec_utilization",
+    "last_local_util_mean", "last_qos_violation", "last_delay_mean", "last_energy_mean",
+)
+
+_LANES = C.c_double * MAX_LANES
+
+
+class RisVecParams(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("struct_bytes", C.c_uint32),
+        ("bandwidth_mhz", C.c_float), ("noise_power", C.c_float), ("p_max", C.c_float),
+        ("power_scale", C.c_float),
+        ("qos_enable", C.c_int32), ("r_min_bpshz", C.c_float), ("d_max_s", C.c_float),
+        ("qos_penalty", C.c_float),
+        ("time_fast", C.c_float), ("k_cpu", C.c_float), ("f_local_max", C.c_float),
+        ("f_edge_max", C.c_float), ("cycles_per_bit", C.c_float), ("cpu_share_floor", C.c_float),
+        ("w_d", C.c_float), ("w_e", C.c_float), ("reward_clip", C.c_float),
+        ("arrival_rate", C.c_float), ("poisson_cdf", C.c_float * POISSON_TABLE),
+        ("fc_ghz", C.c_float), ("shadow_std_los", C.c_float), ("shadow_std_nlos", C.c_float),
+        ("rician_k_db", C.c_float), ("veh_ant_gain", C.c_float), ("n_lanes", C.c_int32),
+        ("time_slow", C.c_double), ("width", C.c_double), ("height", C.c_double),
+        ("lanes_up", _LANES), ("lanes_down", _LANES), ("lanes_left", _LANES), ("lanes_right", _LANES),
+    ]
+
+
+_FP = C.c_void_p
+
+
+class RisVecState(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("struct_bytes", C.c_uint32),
+        ("n_envs", C.c_int32), ("n_veh", C.c_int32), ("n_ris", C.c_int32), ("control_bit", C.c_int32),
+        ("env_offset", C.c_int64),
+        ("pos", _FP), ("dir", _FP), ("vel", _FP),
+        ("dist_r", _FP), ("ang_r", _FP), ("pl", _FP), ("h_r", _FP),
+        ("theta", _FP), ("b", _FP), ("h_d", _FP), ("gain", _FP),
+        ("data_buf", _FP), ("mec_q", _FP),
+        ("rate", _FP), ("data_t", _FP), ("data_p", _FP), ("reward", _FP), ("over_power", _FP),
+        ("obs", _FP), ("metrics", _FP), ("power_w", _FP),
+    ]
+
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librisvec.so")
+
+_PROTOS = {
+    "risvec_abi_version": (C.c_uint32, []),
+    "risvec_last_error": (C.c_char_p, []),
+    "risvec_default_params": (None, [C.POINTER(RisVecParams)]),
+    "risvec_reset": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP,
+                               C.c_uint64, C.c_uint32, _FP]),
+    "risvec_mobility": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP,
+                                  C.c_uint64, C.c_uint32, _FP]),
+    "risvec_geometry": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP]),
+    "risvec_gain": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP]),
+    "risvec_gain_3gpp": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), C.c_int32,
+                                   _FP, _FP, _FP, C.c_uint64, C.c_uint32, _FP]),
+    "risvec_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP]),
+    "risvec_set_phase": (C.c_int, [C.POINTER(RisVecState), _FP, _FP]),
+    "risvec_random_phase": (C.c_int, [C.POINTER(RisVecState), _FP, C.c_uint64, C.c_uint32, _FP]),
+    "risvec_step": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP, _FP, _FP,
+                              C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
+    "risvec_data_rate": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP, _FP, _FP, _FP]),
+    "risvec_step_fused": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP, _FP,
+                                    _FP, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
+    "risvec_step_fused_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP,
+                                        _FP, _FP, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
+}
+
+EXPORTS = tuple(_PROTOS)   # every symbol include/risvec.h declares
+
+_lib = None
+
+
+def load():
+    """Load librisvec.so (once) and return the ctypes handle; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            "ris_vec_marl_amd: HIP extension not built (%s missing). Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C ris_vec_marl_amd/csrc`. "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.risvec_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("librisvec.so ABI %d != binding ABI %d (rebuild)" % (got, ABI_VERSION))
+    if C.sizeof(RisVecParams) != _sizeof_check(lib):
+        raise RuntimeError("RisVecParams layout mismatch between ctypes and librisvec.so")
+    _lib = lib
+    return lib
+
+
+def _sizeof_check(lib) -> int:
+    p = RisVecParams()
+    lib.risvec_default_params(C.byref(p))
+    return int(p.struct_bytes)
+
+
+class RisVecError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("librisvec error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        msg = load().risvec_last_error()
+        err = RisVecError(rc, msg.decode() if msg else "?")
+        if rc in (ERR_ARG, ERR_SHAPE):
+            raise ValueError(str(err)) from err
+        raise err

@@ -1,0 +1,257 @@
+// C ABI of librisvec.so (declared in include/risvec.h): argument validation, error
+// strings, and dispatch to the kernel launchers.  Nothing here computes on the CPU:
+// every entry point either launches HIP kernels or fails with an error code.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "risvec_launch.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define REQ_PTR(ptr, name)                                                                   \
+    do {                                                                                     \
+        if ((ptr) == nullptr) return fail(RISVEC_ERR_ARG, "%s: %s is NULL", fn, name);       \
+        if (!aligned16(ptr)) return fail(RISVEC_ERR_ARG, "%s: %s is not 16-byte aligned", fn, name); \
+    } while (0)
+#define OPT_PTR(ptr, name)                                                                   \
+    do {                                                                                     \
+        if ((ptr) != nullptr && !aligned16(ptr))                                             \
+            return fail(RISVEC_ERR_ARG, "%s: %s is not 16-byte aligned", fn, name);          \
+    } while (0)
+
+int check_common(const char* fn, const RisVecState* s, const RisVecParams* p) {
+    if (!s) return fail(RISVEC_ERR_ARG, "%s: state is NULL", fn);
+    if (s->abi_version != RISVEC_ABI_VERSION || s->struct_bytes != sizeof(RisVecState))
+        return fail(RISVEC_ERR_ARG, "%s: RisVecState ABI mismatch (version %u/%u, bytes %u/%zu)", fn,
+                    s->abi_version, (unsigned)RISVEC_ABI_VERSION, s->struct_bytes, sizeof(RisVecState));
+    if (p && (p->abi_version != RISVEC_ABI_VERSION || p->struct_bytes != sizeof(RisVecParams)))
+        return fail(RISVEC_ERR_ARG, "%s: RisVecParams ABI mismatch (version %u/%u, bytes %u/%zu)", fn,
+                    p->abi_version, (unsigned)RISVEC_ABI_VERSION, p->struct_bytes, sizeof(RisVecParams));
+    if (s->n_envs < 1) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d must be >= 1", fn, s->n_envs);
+    if (s->n_veh < 1 || s->n_veh > RISVEC_MAX_VEH)
+        return fail(RISVEC_ERR_SHAPE, "%s: n_veh=%d outside [1,%d]", fn, s->n_veh, RISVEC_MAX_VEH);
+    if (s->n_ris < 1 || s->n_ris > 2048)
+        return fail(RISVEC_ERR_SHAPE, "%s: n_ris=%d outside [1,2048]", fn, s->n_ris);
+    if (s->control_bit < 0 || s->control_bit > 6)
+        return fail(RISVEC_ERR_SHAPE, "%s: control_bit=%d outside [0,6]", fn, s->control_bit);
+    if ((long long)s->n_envs * s->n_veh * s->n_ris > (1LL << 40))
+        return fail(RISVEC_ERR_SHAPE, "%s: E*V*M too large", fn);
+    if (s->env_offset < 0 || s->env_offset + s->n_envs > 0xFFFFFFFFLL)
+        return fail(RISVEC_ERR_SHAPE, "%s: env_offset+n_envs must fit 32 bits", fn);
+    if (p && (p->n_lanes < 1 || p->n_lanes > RISVEC_MAX_LANES))
+        return fail(RISVEC_ERR_SHAPE, "%s: n_lanes=%d outside [1,%d]", fn, p->n_lanes, RISVEC_MAX_LANES);
+    return RISVEC_OK;
+}
+
+int finish(const char* fn, hipError_t err) {
+    if (err != hipSuccess) return fail(RISVEC_ERR_LAUNCH, "%s: %s", fn, hipGetErrorString(err));
+    return RISVEC_OK;
+}
+
+int check_step(const char* fn, const RisVecState* s, const float* action, const int32_t* partner,
+               const int32_t* n_groups, const int32_t* arrivals, uint32_t flags, bool fused) {
+    REQ_PTR(action, "action"); REQ_PTR(partner, "partner"); REQ_PTR(n_groups, "n_groups");
+    OPT_PTR(arrivals, "arrivals");
+    REQ_PTR(s->gain, "state.gain"); REQ_PTR(s->data_buf, "state.data_buf"); REQ_PTR(s->mec_q, "state.mec_q");
+    REQ_PTR(s->rate, "state.rate"); REQ_PTR(s->data_t, "state.data_t"); REQ_PTR(s->data_p, "state.data_p");
+    REQ_PTR(s->reward, "state.reward"); REQ_PTR(s->over_power, "state.over_power");
+    REQ_PTR(s->metrics, "state.metrics");
+    if (flags & RISVEC_STEP_OBS) REQ_PTR(s->obs, "state.obs");
+    if (flags & RISVEC_STEP_POWER_W) REQ_PTR(s->power_w, "state.power_w");
+    if (flags & ~(uint32_t)(RISVEC_STEP_METRICS | RISVEC_STEP_POWER_W | RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS))
+        return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
+    if (fused) {
+        REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->b, "state.b");
+        REQ_PTR(s->pl, "state.pl"); OPT_PTR(s->h_d, "state.h_d");
+    }
+    return RISVEC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t risvec_abi_version(void) { return RISVEC_ABI_VERSION; }
+
+const char* risvec_last_error(void) { return g_err; }
+
+void risvec_default_params(RisVecParams* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->abi_version = RISVEC_ABI_VERSION;
+    p->struct_bytes = sizeof(RisVecParams);
+    p->bandwidth_mhz = 1.0f;                                           // ENV:72
+    p->noise_power = (float)(std::pow(10.0, (-174.0 - 30.0) / 10.0) * 1.0e6);   // ENV:74-76
+    p->p_max = 1.0f;                                                   // ENV:125
+    p->power_scale = 0.7f;                                             // ENV:555
+    p->qos_enable = 1; p->r_min_bpshz = 0.20f; p->d_max_s = 0.10f; p->qos_penalty = 5.0f;   // ENV:79-82
+    p->time_fast = 1e-3f;                                              // ENV:102
+    p->k_cpu = 1e-28f;                                                 // ENV:104
+    p->f_local_max = 1.0e9f; p->f_edge_max = 2.0e9f;                   // ENV:108-109
+    p->cycles_per_bit = 500.0f; p->cpu_share_floor = 0.10f;            // ENV:111-113
+    p->w_d = 0.5f; p->w_e = 3.0f; p->reward_clip = 50.0f;              // ENV:138-143
+    p->arrival_rate = 3.0f;                                            // ENV:156
+    {   // Poisson(3) CDF, float64 -> float32
+        double pk = std::exp(-3.0), cdf = 0.0;
+        for (int k = 0; k < RISVEC_POISSON_TABLE; ++k) {
+            cdf += pk;
+            p->poisson_cdf[k] = (float)(cdf < 1.0 ? cdf : 1.0);
+            pk *= 3.0 / (double)(k + 1);
+        }
+    }
+    p->fc_ghz = 3.5f; p->shadow_std_los = 4.0f; p->shadow_std_nlos = 7.0f;   // ENV:186-188
+    p->rician_k_db = 0.0f; p->veh_ant_gain = 3.0f;                     // ENV:189, 96
+    p->n_lanes = 4;
+    p->time_slow = 0.1; p->width = 400.0; p->height = 400.0;           // ENV:101
+    const double up[4] = {(400 + 3.5 / 2) / 2.0, (400 + 3.5 + 3.5 / 2) / 2.0, (800 + 3.5 / 2) / 2.0,
+                          (800 + 3.5 + 3.5 / 2) / 2.0};                // marl_train_bcd.py:446
+    const double dn[4] = {(400 - 3.5 - 3.5 / 2) / 2.0, (400 - 3.5 / 2) / 2.0, (800 - 3.5 - 3.5 / 2) / 2.0,
+                          (800 - 3.5 / 2) / 2.0};                      // marl_train_bcd.py:447
+    for (int i = 0; i < 4; ++i) {
+        p->lanes_up[i] = up[i]; p->lanes_left[i] = up[i];
+        p->lanes_down[i] = dn[i]; p->lanes_right[i] = dn[i];
+    }
+}
+
+int risvec_reset(const RisVecState* s, const RisVecParams* p, const int32_t* spawn_ints,
+                 const int32_t* buf0, uint64_t seed, uint32_t counter, risvec_stream_t stream) {
+    const char* fn = "risvec_reset";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    REQ_PTR(s->pos, "state.pos"); REQ_PTR(s->dir, "state.dir"); REQ_PTR(s->vel, "state.vel");
+    REQ_PTR(s->data_buf, "state.data_buf");
+    OPT_PTR(spawn_ints, "spawn_ints"); OPT_PTR(buf0, "buf0");
+    if ((spawn_ints == nullptr) != (buf0 == nullptr))
+        return fail(RISVEC_ERR_ARG, "%s: spawn_ints and buf0 must both be given or both be NULL", fn);
+    if (p->n_lanes != 4)
+        return fail(RISVEC_ERR_UNSUPPORTED, "%s: the reference spawn rule is defined for 4 lanes per direction", fn);
+    return finish(fn, risvec::launch_reset(*s, *p, spawn_ints, buf0, seed, counter, (hipStream_t)stream));
+}
+
+int risvec_mobility(const RisVecState* s, const RisVecParams* p, const float* u_turn, int32_t* n_used,
+                    uint64_t seed, uint32_t counter, risvec_stream_t stream) {
+    const char* fn = "risvec_mobility";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    REQ_PTR(s->pos, "state.pos"); REQ_PTR(s->dir, "state.dir"); REQ_PTR(s->vel, "state.vel");
+    OPT_PTR(u_turn, "u_turn"); OPT_PTR(n_used, "n_used");
+    return finish(fn, risvec::launch_mobility(*s, *p, u_turn, n_used, seed, counter, (hipStream_t)stream));
+}
+
+int risvec_geometry(const RisVecState* s, const RisVecParams* p, risvec_stream_t stream) {
+    const char* fn = "risvec_geometry";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    REQ_PTR(s->pos, "state.pos"); REQ_PTR(s->dist_r, "state.dist_r"); REQ_PTR(s->ang_r, "state.ang_r");
+    REQ_PTR(s->pl, "state.pl"); REQ_PTR(s->h_r, "state.h_r");
+    return finish(fn, risvec::launch_geometry(*s, *p, (hipStream_t)stream));
+}
+
+int risvec_gain(const RisVecState* s, const RisVecParams* p, risvec_stream_t stream) {
+    const char* fn = "risvec_gain";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->b, "state.b");
+    REQ_PTR(s->pl, "state.pl"); REQ_PTR(s->gain, "state.gain"); OPT_PTR(s->h_d, "state.h_d");
+    return finish(fn, risvec::launch_gain(*s, *p, (hipStream_t)stream));
+}
+
+int risvec_gain_3gpp(const RisVecState* s, const RisVecParams* p, int32_t model, const float* u_los,
+                     const float* z_shadow, const float* small, uint64_t seed, uint32_t counter,
+                     risvec_stream_t stream) {
+    const char* fn = "risvec_gain_3gpp";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    if (model != RISVEC_CH_3GPP_UMI && model != RISVEC_CH_3GPP_UMA && model != RISVEC_CH_OTHER)
+        return fail(RISVEC_ERR_ARG, "%s: model=%d is not a 3GPP/other model (use risvec_gain for 'free')", fn, model);
+    REQ_PTR(s->pos, "state.pos"); REQ_PTR(s->gain, "state.gain");
+    OPT_PTR(u_los, "u_los"); OPT_PTR(z_shadow, "z_shadow"); OPT_PTR(small, "small");
+    const int n_inj = (u_los != nullptr) + (z_shadow != nullptr) + (small != nullptr);
+    if (n_inj != 0 && n_inj != 3)
+        return fail(RISVEC_ERR_ARG, "%s: u_los, z_shadow, small must all be given or all be NULL", fn);
+    return finish(fn, risvec::launch_gain_3gpp(*s, *p, model, u_los, z_shadow, small, seed, counter,
+                                               (hipStream_t)stream));
+}
+
+int risvec_bcd(const RisVecState* s, const RisVecParams* p, int32_t* idx_out, risvec_stream_t stream) {
+    const char* fn = "risvec_bcd";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->b, "state.b");
+    OPT_PTR(idx_out, "idx_out");
+    return finish(fn, risvec::launch_bcd(*s, *p, idx_out, (hipStream_t)stream));
+}
+
+int risvec_set_phase(const RisVecState* s, const float* angle, risvec_stream_t stream) {
+    const char* fn = "risvec_set_phase";
+    if (int rc = check_common(fn, s, nullptr)) return rc;
+    REQ_PTR(angle, "angle"); REQ_PTR(s->theta, "state.theta");
+    return finish(fn, risvec::launch_set_phase(*s, angle, (hipStream_t)stream));
+}
+
+int risvec_random_phase(const RisVecState* s, const int32_t* idx, uint64_t seed, uint32_t counter,
+                        risvec_stream_t stream) {
+    const char* fn = "risvec_random_phase";
+    if (int rc = check_common(fn, s, nullptr)) return rc;
+    OPT_PTR(idx, "idx"); REQ_PTR(s->theta, "state.theta");
+    return finish(fn, risvec::launch_random_phase(*s, idx, seed, counter, (hipStream_t)stream));
+}
+
+int risvec_step(const RisVecState* s, const RisVecParams* p, const float* action, const int32_t* partner,
+                const int32_t* n_groups, const int32_t* arrivals, uint64_t seed, uint32_t counter,
+                uint32_t flags, risvec_stream_t stream) {
+    const char* fn = "risvec_step";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    if (int rc = check_step(fn, s, action, partner, n_groups, arrivals, flags, false)) return rc;
+    return finish(fn, risvec::launch_step(*s, *p, action, partner, n_groups, arrivals, seed, counter, flags,
+                                          false, (hipStream_t)stream));
+}
+
+int risvec_data_rate(const RisVecState* s, const RisVecParams* p, const float* p_off, const int32_t* partner,
+                     const int32_t* n_groups, float* rate_out, risvec_stream_t stream) {
+    const char* fn = "risvec_data_rate";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    REQ_PTR(p_off, "p_off"); REQ_PTR(partner, "partner"); REQ_PTR(n_groups, "n_groups");
+    REQ_PTR(rate_out, "rate_out"); REQ_PTR(s->gain, "state.gain");
+    return finish(fn, risvec::launch_data_rate(*s, *p, p_off, partner, n_groups, rate_out, (hipStream_t)stream));
+}
+
+int risvec_step_fused(const RisVecState* s, const RisVecParams* p, const float* action,
+                      const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals,
+                      uint64_t seed, uint32_t counter, uint32_t flags, risvec_stream_t stream) {
+    const char* fn = "risvec_step_fused";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    if (int rc = check_step(fn, s, action, partner, n_groups, arrivals, flags, true)) return rc;
+    return finish(fn, risvec::launch_step(*s, *p, action, partner, n_groups, arrivals, seed, counter, flags,
+                                          true, (hipStream_t)stream));
+}
+
+int risvec_step_fused_bcd(const RisVecState* s, const RisVecParams* p, const float* action,
+                          const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals,
+                          uint64_t seed, uint32_t counter, uint32_t flags, risvec_stream_t stream) {
+    const char* fn = "risvec_step_fused_bcd";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    if (int rc = check_step(fn, s, action, partner, n_groups, arrivals, flags, true)) return rc;
+    return finish(fn, risvec::launch_step_fused_bcd(*s, *p, action, partner, n_groups, arrivals, seed,
+                                                    counter, flags, (hipStream_t)stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// Internal launcher declarations (one per kernel family); argument validation lives
+// in risvec_api.hip, these only compute the grid and launch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "risvec.h"
+#include "risvec_dev.hpp"
+
+namespace risvec {
+
+hipError_t launch_reset(const RisVecState& s, const RisVecParams& p, const int32_t* spawn_ints,
+                        const int32_t* buf0, uint64_t seed, uint32_t counter, hipStream_t st);
+hipError_t launch_mobility(const RisVecState& s, const RisVecParams& p, const float* u_turn,
+                           int32_t* n_used, uint64_t seed, uint32_t counter, hipStream_t st);
+hipError_t launch_geometry(const RisVecState& s, const RisVecParams& p, hipStream_t st);
+hipError_t launch_gain_3gpp(const RisVecState& s, const RisVecParams& p, int32_t model,
+                            const float* u_los, const float* z_shadow, const float* small,
+                            uint64_t seed, uint32_t counter, hipStream_t st);
+hipError_t launch_set_phase(const RisVecState& s, const float* angle, hipStream_t st);
+hipError_t launch_random_phase(const RisVecState& s, const int32_t* idx, uint64_t seed,
+                               uint32_t counter, hipStream_t st);
+
+hipError_t launch_gain(const RisVecState& s, const RisVecParams& p, hipStream_t st);
+hipError_t launch_step(const RisVecState& s, const RisVecParams& p, const float* action,
+                       const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals,
+                       uint64_t seed, uint32_t counter, uint32_t flags, bool fused, hipStream_t st);
+
+hipError_t launch_data_rate(const RisVecState& s, const RisVecParams& p, const float* p_off,
+                            const int32_t* partner, const int32_t* n_groups, float* rate_out,
+                            hipStream_t st);
+
+hipError_t launch_bcd(const RisVecState& s, const RisVecParams& p, int32_t* idx_out, hipStream_t st);
+hipError_t launch_step_fused_bcd(const RisVecState& s, const RisVecParams& p, const float* action,
+                                 const int32_t* partner, const int32_t* n_groups,
+                                 const int32_t* arrivals, uint64_t seed, uint32_t counter,
+                                 uint32_t flags, hipStream_t st);
+
+inline Dims dims_of(const RisVecState& s) {
+    return Dims{s.n_envs, s.n_veh, s.n_ris, s.control_bit, (long long)s.env_offset};
+}
+
+}  // namespace risvec

@@ -1,0 +1,364 @@
+"""`VecEnviron`: E independent RIS-VEC environments resident on one MI355X.
+
+Host-side mirror of the reference's `Environ` class (Environment.py:56) for the hot
+path only: same method names, same argument meaning, batched over a leading env
+axis and returning torch tensors that live on the GPU.  All arithmetic happens in
+the HIP kernels of `csrc/` behind the C ABI of `include/risvec.h`; torch is used
+for device memory and streams.  There is no CPU fallback: without a HIP device (or
+without the built extension) every compute call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .params import CHANNEL_MODELS, EnvParams
+
+# module constants of the reference (Environment.py:29-42)
+RIS_x, RIS_y, RIS_z = 220, 220, 25
+BS_x, BS_y, BS_z = 0, 0, 25
+ro = 10 ** -2
+lamb = 1
+d = 0.5
+sigma = 10 ** (-7)
+alpha1 = 2.2
+alpha2 = 2.5
+
+
+class ParamAttrs:
+    """Gives an env object the reference's flat attribute surface: `env.w_d = 1.0`,
+    `env.noise_power` ... are forwarded to `self.params` (an `EnvParams`)."""
+
+    def __getattr__(self, name):
+        # only called when normal lookup fails
+        params = self.__dict__.get("params")
+        if params is not None and name in EnvParams._FIELDS:
+            return getattr(params, name)
+        raise AttributeError("%s object has no attribute %r" % (type(self).__name__, name))
+
+    def __setattr__(self, name, value):
+        params = self.__dict__.get("params")
+        if params is not None and name in EnvParams._FIELDS:
+            setattr(params, name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+
+def _dev_ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class VecEnviron(ParamAttrs):
+    """Batched environment.  Constructor mirrors Environment.py:57 plus batching args."""
+
+    def __init__(self, down_lane, up_lane, left_lane, right_lane, width, height, n_veh, M, control_bit,
+                 n_envs: int = 1, device: str = "cuda", seed: int = 0, env_offset: int = 0,
+                 params: Optional[EnvParams] = None):
+        object.__setattr__(self, "params", params if params is not None else EnvParams())
+        self.down_lanes = list(down_lane)
+        self.up_lanes = list(up_lane)
+        self.left_lanes = list(left_lane)
+        self.right_lanes = list(right_lane)
+        self.width = width
+        self.height = height
+        self.n_veh = int(n_veh)
+        self.M = int(M)
+        self.control_bit = int(control_bit)
+        self.n_envs = int(n_envs)
+        self.env_offset = int(env_offset)
+        self.seed = int(seed)
+        self.device = torch.device(device)
+        if not 1 <= self.n_veh <= N.MAX_VEH:
+            raise ValueError("n_veh must be in [1, %d]" % N.MAX_VEH)
+        if self.n_envs < 1 or self.M < 1:
+            raise ValueError("n_envs and M must be >= 1")
+        if not 0 <= self.control_bit <= 6:
+            raise ValueError("control_bit must be in [0, 6]")
+        # Environment.py:169, 175-179
+        self.possible_angles = np.linspace(0, 2 * np.pi, 2 ** self.control_bit, endpoint=False)
+        self.distance_B_R = float(np.sqrt((BS_x - RIS_x) ** 2 + (BS_y - RIS_y) ** 2 + (BS_z - RIS_z) ** 2))
+        self.angle_B_R = (RIS_x - BS_x) / self.distance_B_R
+        m = np.arange(self.M, dtype=np.float64)
+        ph = 2 * (np.pi / lamb) * d * self.angle_B_R * m
+        self.phase_R = np.cos(ph) + 1j * np.sin(ph)
+        self._epoch = 0          # reset counter   (RNG counter for spawn draws)
+        self._moves = 0          # renew_positions counter
+        self._steps = 0          # step counter    (RNG counter for arrivals)
+        self._chan = 0           # 3GPP-gain / random-phase counter
+        self._t: Dict[str, torch.Tensor] = {}
+        self._cstate: Optional[N.RisVecState] = None
+        self._cparams: Optional[N.RisVecParams] = None
+        self._cparams_version = -1
+
+    # ------------------------------------------------------------------ device state
+    def _lanes(self):
+        return dict(up_lanes=self.up_lanes, down_lanes=self.down_lanes, left_lanes=self.left_lanes,
+                    right_lanes=self.right_lanes)
+
+    def _ensure_device(self) -> None:
+        if self._cstate is not None:
+            return
+        lib = N.load()       # raises if the extension is not built
+        del lib
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("ris_vec_marl_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        E, V, M = self.n_envs, self.n_veh, self.M
+        dev = self.device
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=dev)   # noqa: E731
+        t = self._t
+        t["pos"] = z(E, V, 2, dt=torch.float64)
+        t["dir"] = z(E, V, dt=torch.int32)
+        t["vel"] = z(E, V)
+        t["dist_r"] = z(E, V)
+        t["ang_r"] = z(E, V)
+        t["pl"] = z(E, V)
+        t["h_r"] = z(E, V, M, 2)        # all-zero until compute_parms(), like Environment.py:162
+        t["theta"] = z(E, M, 2)         # all-zero start, Environment.py:171
+        t["b"] = torch.from_numpy(np.stack([self.phase_R.real, self.phase_R.imag], -1).astype(np.float32)).to(dev)
+        t["gain"] = z(E, V)
+        t["data_buf"] = z(E, V)
+        t["mec_q"] = z(E)
+        for k in ("rate", "data_t", "data_p", "reward", "over_power", "over_data"):
+            t[k] = z(E, V)
+        t["obs"] = z(E, V, 5)
+        t["metrics"] = z(E, N.METRICS)
+        t["power_w"] = z(E, 2, V)
+        s = N.RisVecState()
+        s.abi_version = N.ABI_VERSION
+        s.struct_bytes = C.sizeof(N.RisVecState)
+        s.n_envs, s.n_veh, s.n_ris, s.control_bit = E, V, M, self.control_bit
+        s.env_offset = self.env_offset
+        for k in ("pos", "dir", "vel", "dist_r", "ang_r", "pl", "h_r", "theta", "b", "gain", "data_buf",
+                  "mec_q", "rate", "data_t", "data_p", "reward", "over_power", "obs", "metrics", "power_w"):
+            setattr(s, k, t[k].data_ptr())
+        s.h_d = None
+        self._cstate = s
+
+    def set_direct_link(self, h_d: Optional[torch.Tensor]) -> None:
+        """Optional direct BS link amplitude h_d [E,V] complex64 (the reference has none:
+        Environment.py:263-273); None restores the reference behaviour."""
+        self._ensure_device()
+        if h_d is None:
+            self._t.pop("h_d", None)
+            self._cstate.h_d = None
+            return
+        h = torch.view_as_real(h_d.to(self.device, torch.complex64)).contiguous()
+        if tuple(h.shape) != (self.n_envs, self.n_veh, 2):
+            raise ValueError("h_d must have shape [n_envs, n_veh]")
+        self._t["h_d"] = h
+        self._cstate.h_d = h.data_ptr()
+
+    def _p(self) -> N.RisVecParams:
+        if self._cparams is None or self._cparams_version != self.params.version:
+            self._cparams = self.params.to_c(self._lanes(), self.width, self.height)
+            self._cparams_version = self.params.version
+        return self._cparams
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _arg(self, x, dtype, shape, name) -> Optional[torch.Tensor]:
+        if x is None:
+            return None
+        tt = torch.as_tensor(x)
+        if tuple(tt.shape) != tuple(shape):
+            raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(tt.shape)))
+        return tt.to(device=self.device, dtype=dtype).contiguous()
+
+    # ------------------------------------------------------------------ tensors (views)
+    @property
+    def tensors(self) -> Dict[str, torch.Tensor]:
+        self._ensure_device()
+        return self._t
+
+    def __getattr__(self, name):
+        t = self.__dict__.get("_t")
+        alias = _TENSOR_ALIASES.get(name)
+        if alias is not None and t is not None:
+            self._ensure_device()
+            return self._t[alias]
+        return ParamAttrs.__getattr__(self, name)
+
+    @property
+    def elements_phase_shift_complex(self) -> torch.Tensor:
+        return torch.view_as_complex(self.tensors["theta"])
+
+    @property
+    def phases_R_i(self) -> torch.Tensor:
+        return torch.view_as_complex(self.tensors["h_r"])
+
+    # ------------------------------------------------------------------ reference methods
+    def make_new_game(self, spawn_ints=None, buf0=None) -> None:
+        """Environment.py:733-737 (+381-410).  Optional injected draws: spawn_ints
+        [E,V,3] int32 (aux, coord, velocity), buf0 [E] int32."""
+        self._ensure_device()
+        E, V = self.n_envs, self.n_veh
+        si = self._arg(spawn_ints, torch.int32, (E, V, 3), "spawn_ints")
+        b0 = self._arg(buf0, torch.int32, (E,), "buf0")
+        self._epoch += 1
+        N.check(N.load().risvec_reset(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(si), _dev_ptr(b0),
+                                      self.seed, self._epoch, self._stream()))
+
+    def renew_positions(self, u_turn=None, return_n_used: bool = False):
+        """Environment.py:412-542.  u_turn [E,V,8] float32 injected uniform draws."""
+        self._ensure_device()
+        E, V = self.n_envs, self.n_veh
+        u = self._arg(u_turn, torch.float32, (E, V, 8), "u_turn")
+        nu = torch.zeros(E, V, dtype=torch.int32, device=self.device) if return_n_used else None
+        self._moves += 1
+        N.check(N.load().risvec_mobility(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(u), _dev_ptr(nu),
+                                         self.seed, self._moves, self._stream()))
+        return nu
+
+    def compute_parms(self) -> None:
+        """Environment.py:241-253: pos -> distances_R_i, angles_R_i, phases_R_i (+ path-loss factor)."""
+        self._ensure_device()
+        N.check(N.load().risvec_geometry(C.byref(self._cstate), C.byref(self._p()), self._stream()))
+
+    def optimize_phase_shift(self, return_idx: bool = False):
+        """Environment.py:208-220 (one BCD sweep, objective of :222-231)."""
+        self._ensure_device()
+        idx = torch.zeros(self.n_envs, self.M, dtype=torch.int32, device=self.device) if return_idx else None
+        N.check(N.load().risvec_bcd(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(idx), self._stream()))
+        return idx
+
+    def update_channel_gains(self, u_los=None, z_shadow=None, small=None) -> None:
+        """Environment.py:255-327, dispatching on `channel_model` like the reference
+        (unknown keywords fall back to a 0 dB path loss, :315-317)."""
+        self._ensure_device()
+        model = str(self.params.channel_model)
+        if model == "free":
+            N.check(N.load().risvec_gain(C.byref(self._cstate), C.byref(self._p()), self._stream()))
+            return
+        E, V = self.n_envs, self.n_veh
+        ul = self._arg(u_los, torch.float32, (E, V), "u_los")
+        zs = self._arg(z_shadow, torch.float32, (E, V), "z_shadow")
+        sm = self._arg(small, torch.float32, (E, V), "small")
+        self._chan += 1
+        N.check(N.load().risvec_gain_3gpp(C.byref(self._cstate), C.byref(self._p()),
+                                          CHANNEL_MODELS.get(model, N.CH_OTHER), _dev_ptr(ul), _dev_ptr(zs),
+                                          _dev_ptr(sm), self.seed, self._chan, self._stream()))
+
+    def get_channel_gains(self) -> torch.Tensor:
+        """Environment.py:374-376."""
+        return self.tensors["gain"]
+
+    def get_next_phase(self, action_phase) -> None:
+        """Environment.py:233-239: theta = exp(j * angle), angle [E,M]."""
+        self._ensure_device()
+        a = self._arg(action_phase, torch.float32, (self.n_envs, self.M), "action_phase")
+        N.check(N.load().risvec_set_phase(C.byref(self._cstate), _dev_ptr(a), self._stream()))
+
+    def Random_phase(self, idx=None) -> None:
+        """Environment.py:203-206; idx [E,M] int32 indices into possible_angles (optional)."""
+        self._ensure_device()
+        i = self._arg(idx, torch.int32, (self.n_envs, self.M), "idx")
+        self._chan += 1
+        N.check(N.load().risvec_random_phase(C.byref(self._cstate), _dev_ptr(i), self.seed, self._chan,
+                                             self._stream()))
+
+    def data_rate(self, p_off, partner, n_groups) -> torch.Tensor:
+        """Environment.py:331-372 on the cached gains: p_off [E,V] offload power in W -> rate [E,V]."""
+        self._ensure_device()
+        E, V = self.n_envs, self.n_veh
+        pw = self._arg(p_off, torch.float32, (E, V), "p_off")
+        pt = self._arg(partner, torch.int32, (E, V), "partner")
+        ng = self._arg(n_groups, torch.int32, (E,), "n_groups")
+        out = torch.empty(E, V, dtype=torch.float32, device=self.device)
+        N.check(N.load().risvec_data_rate(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(pw), _dev_ptr(pt),
+                                          _dev_ptr(ng), _dev_ptr(out), self._stream()))
+        return out
+
+    def step(self, action_power, partner, n_groups, arrivals=None, fused: bool = False, bcd: bool = False,
+             metrics: bool = True, power_w: bool = True, obs: bool = True, policy_action: bool = False
+             ) -> Tuple[torch.Tensor, ...]:
+        """Environment.py:547-731 for every env.
+
+        action_power [E,2,V] float32 (or the policy output [E,V,2] with policy_action=True,
+        marl_train_bcd.py:1601-1608); partner [E,V] int32 / n_groups [E] int32 encode
+        `noma_groups` (see `compat.encode_noma_groups`); arrivals [E,V] int32 = injected
+        Poisson draws (None: in-kernel Philox).  fused=True recomputes the RIS cascaded
+        gains in the same launch (the north-star kernel); bcd=True additionally runs a BCD
+        sweep first.  Returns the reference's 7-tuple, batched:
+        (per_user_reward [E,V], global_reward [E], DataBuf, data_t, data_p, over_power, over_data);
+        the tensors are owned by the env and overwritten by the next step."""
+        self._ensure_device()
+        E, V = self.n_envs, self.n_veh
+        a = self._arg(action_power, torch.float32, (E, V, 2) if policy_action else (E, 2, V), "action_power")
+        pt = self._arg(partner, torch.int32, (E, V), "partner")
+        ng = self._arg(n_groups, torch.int32, (E,), "n_groups")
+        ar = self._arg(arrivals, torch.int32, (E, V), "arrivals")
+        flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
+                 | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0))
+        lib = N.load()
+        fn = lib.risvec_step_fused_bcd if bcd else (lib.risvec_step_fused if fused else lib.risvec_step)
+        N.check(fn(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng),
+                   _dev_ptr(ar), self.seed, self._steps, flags, self._stream()))
+        self._steps += 1
+        t = self._t
+        return (t["reward"], t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"],
+                t["over_data"])
+
+    # ------------------------------------------------------------------ driver-side helpers
+    def observe(self) -> torch.Tensor:
+        """marl_train_bcd.py:819-827 for all agents: [E,V,5].  After a step the kernel has
+        already written it; before the first step it is assembled from the state."""
+        t = self.tensors
+        if self._steps == 0:
+            o = t["obs"]
+            o.zero_()
+            o[..., 0] = t["data_buf"] / 10
+        return t["obs"]
+
+    def metrics_dict(self) -> Dict[str, torch.Tensor]:
+        """The 13 `last_*` scalars + global_reward, each [E] (Environment.py:612-677, 706-711)."""
+        m = self.tensors["metrics"]
+        return {name: m[:, i] for i, name in enumerate(N.METRIC_NAMES)}
+
+    def begin_episode(self, i_episode: int, env_refresh_every: int = 5) -> bool:
+        """Call cadence of marl_train_bcd.py:1268-1271."""
+        if i_episode % max(1, int(env_refresh_every)) == 0:
+            self.renew_positions()
+            self.compute_parms()
+            return True
+        return False
+
+    def begin_step(self, i_step: int, ris_every: int = 100) -> bool:
+        """Call cadence of marl_train_bcd.py:1307-1309 (K_STEPS_FOR_RIS_OPTIMIZATION = 100)."""
+        if i_step % max(1, int(ris_every)) == 0:
+            self.optimize_phase_shift()
+            self.update_channel_gains()
+            return True
+        return False
+
+    # ------------------------------------------------------------------ checkpoint
+    _STATE_KEYS = ("pos", "dir", "vel", "dist_r", "ang_r", "pl", "h_r", "theta", "gain", "data_buf", "mec_q",
+                   "rate", "data_t", "data_p")
+
+    def state_dict(self) -> Dict[str, object]:
+        t = self.tensors
+        sd: Dict[str, object] = {k: t[k].detach().cpu().clone() for k in self._STATE_KEYS}
+        sd["counters"] = dict(epoch=self._epoch, moves=self._moves, steps=self._steps, chan=self._chan,
+                              seed=self.seed, env_offset=self.env_offset)
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        t = self.tensors
+        for k in self._STATE_KEYS:
+            t[k].copy_(sd[k])
+        c = sd["counters"]
+        self._epoch, self._moves, self._steps, self._chan = c["epoch"], c["moves"], c["steps"], c["chan"]
+
+
+# reference attribute name -> tensor key
+_TENSOR_ALIASES = {
+    "DataBuf": "data_buf", "data_t": "data_t", "data_p": "data_p", "over_data": "over_data",
+    "vehicle_rate": "rate", "channel_gains": "gain", "distances_R_i": "dist_r", "angles_R_i": "ang_r",
+    "mec_queue_cycles": "mec_q", "last_power_W": "power_w", "positions": "pos", "directions": "dir",
+    "velocities": "vel",
+}
