@@ -1,0 +1,77 @@
+"""world_size-2 `gloo` test of the multi-GPU layer on CPU: env ids shard by rank with no
+data-path collective, the ONE exchange is the joint-observation all-gather, and results
+are independent of the sharding (RNG keyed by global env id).  The per-shard env work is
+done by the CPU oracle here (the product has no CPU path); what is under test is
+`ris_vec_marl_amd.dist` and the sharding contract."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+from oracle import risvec_oracle as orc
+
+E, V, SEED, STEPS = 64, 8, 2024, 3
+
+
+def shard_obs(lo, hi):
+    """obs [hi-lo, V, 5] after STEPS oracle steps for global env ids lo..hi-1."""
+    ids = np.arange(lo, hi)
+    rng = np.random.default_rng(7)                    # same full-batch inputs on every rank
+    gain = 10 ** rng.uniform(-13, -10, (E, V))
+    action = rng.uniform(0, 1, (E, 2, V))
+    p = orc.OracleParams.yaml_effective()
+    buf, q = np.full((hi - lo, V), 3.0), np.zeros(hi - lo)
+    partner = np.full((hi - lo, V), -1); ng = np.full(hi - lo, V)
+    o = None
+    for s in range(STEPS):
+        arr = orc.philox_arrivals(ids, V, s, SEED, p.rate)
+        o = orc.step(buf, q, gain[lo:hi], action[lo:hi], partner, ng, arr, p)
+        buf, q = o["data_buf"], o["mec_q"]
+    return o["obs"].astype(np.float32)
+
+
+def worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ris_vec_marl_amd import dist as rdist
+    r, w, _ = rdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    lo, n = rdist.shard_range(E, rank, world)
+    obs_local = torch.from_numpy(shard_obs(lo, lo + n))
+    g = rdist.JointObsGather(n, V, "cpu")
+    a = g.start(obs_local); g.wait()
+    b = g.start(obs_local * 2); g.wait()             # second buffer of the double buffer
+    joint = rdist.gather_joint_obs(obs_local)
+    if rank == 0:
+        out.put((a.numpy().copy(), b.numpy().copy(), joint.numpy().copy()))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_joint_obs_allgather_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    a, b, joint = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = shard_obs(0, E).reshape(E, 5 * V)         # one rank owning every env
+    assert a.shape == (E, 5 * V)
+    np.testing.assert_array_equal(a, whole)           # sharded == unsharded, bit for bit
+    np.testing.assert_array_equal(b, whole * 2)
+    np.testing.assert_array_equal(joint, whole)
+
+
+def test_single_process_gather_is_a_copy():
+    from ris_vec_marl_amd import dist as rdist
+    x = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)
+    y = rdist.gather_joint_obs(x)
+    assert y.shape == (2, 15) and torch.equal(y, x.reshape(2, 15))
