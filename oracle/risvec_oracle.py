@@ -576,7 +576,7 @@ def step(data_buf: np.ndarray, mec_q: np.ndarray, gain: np.ndarray, action: np.n
     return dict(reward=reward, global_reward=g_reward, data_buf=B_new, data_t=data_t,
                 data_p=data_p, over_power=over_power, over_data=over_data,
                 vehicle_rate=rate, mec_q=Q, metrics=metrics, last_power_W=last_power_W,
-                obs=obs, delay=delay, viol=viol, power_W=power_W,
+                obs=obs, delay=delay, viol=viol, power_W=power_W, ein_sum=ein_sum,
                 # distances to the discontinuities, for near-threshold tagging in tests
                 margin=dict(rate=rate - p.R_min_bpsHz, delay=delay - p.D_max_s,
                             s=s[:, 0, :] - 1.0, raw_reward=-cost - pen))
