@@ -131,6 +131,7 @@ def main() -> None:
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N>1: all-gather the joint observation every k steps (0 = never)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true", help="experiment: skip metrics and obs writes")
     ap.add_argument("--mode", default="fused", choices=["fused", "cached", "bcd"],
                     help="fused: gains+step each step (headline); cached: step only (reference cadence); "
                          "bcd: BCD sweep + gains + step each step (BASELINE config 5)")
@@ -169,7 +170,7 @@ def main() -> None:
     fused, bcd = args.mode != "cached", args.mode == "bcd"
 
     def one_step(i: int) -> None:
-        env.step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=True, power_w=False, obs=True)
+        env.step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=not args.lean, power_w=False, obs=not args.lean)
         if gather is not None and i % args.gather_every == 0:
             gather.wait()
             gather.start(env.tensors["obs"])

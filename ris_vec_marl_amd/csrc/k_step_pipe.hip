@@ -1,0 +1,264 @@
+// K34, compile-time shapes: the fused "RIS cascaded gains + step()" kernel as a software
+// pipeline.  Same results as the generic k_step_fused (k_step.hip), restructured so the
+// HBM stream never waits for the step arithmetic:
+//
+//   * a wave owns SEVERAL groups of 64/VP envs (grid-strided), not one: while it runs
+//     step() for group g, the h_r/theta loads of group g+1 are already in flight;
+//   * loads are issued D "units" ahead (a unit = up to 4 vehicle rows of one env, i.e. up to
+//     8 x 16-byte loads per lane) into a register ring that is indexed at compile time;
+//   * the K = 2*PC per-lane partial sums of a unit (re/im of PC rows) are reduced with a
+//     TRANSPOSING butterfly: at each of the first log2(K) steps a lane hands half of its
+//     values to its partner and keeps the other half, so K values cost K-1 exchanges
+//     instead of K*log2(G); exchanges at distance 1, 2, 4, 8 are DPP (plain VALU);
+//   * step() inputs are fetched at the top of the group, long before they are needed.
+//
+// Reference: Simulation-MARL-BCD/Environment.py update_channel_gains ENV:263-273 + step
+// ENV:547-731 (see risvec_step.hpp).
+#include <cstdlib>
+
+#include "risvec_step.hpp"
+
+namespace risvec {
+
+template <int V, int M>
+struct PipeShape {
+    static constexpr int VP = pow2_ceil(V);
+    static_assert(V == VP, "pipelined kernels are instantiated for power-of-two V");
+    static_assert(M % 2 == 0, "pipelined kernels need an even M (16-byte loads)");
+    static constexpr int EPW = kWave / VP;                     // envs per group
+    static constexpr int NP = M / 2;                           // complex pairs per row
+    static constexpr int G0 = pow2_ceil(NP) > kWave ? kWave : pow2_ceil(NP);
+    static constexpr int GMIN = (kWave / VP) < 8 ? 8 : (kWave / VP);
+    static constexpr int G = G0 < GMIN ? GMIN : G0;            // lanes per row
+    static constexpr int NIT = (NP + G - 1) / G;               // 16-B loads per lane per row
+    static constexpr int VPP = kWave / G;                      // rows per pass
+    static constexpr int PASSES = V / VPP;
+    static_assert(PASSES * VPP == V, "rows per pass must divide V");
+    static constexpr int PC = PASSES >= 4 ? 4 : PASSES;        // rows per unit per lane-group
+    static constexpr int CHUNKS = PASSES / PC;
+    static_assert(CHUNKS * PC == PASSES, "PASSES must be a multiple of PC");
+    static constexpr int UPG = EPW * CHUNKS;                   // units per group
+    static constexpr int K = 2 * PC;                           // values reduced per unit
+    static constexpr int WSTRIDE = G / K;                      // writer lanes: gl % WSTRIDE == 0
+    static_assert(G >= K, "need at least K lanes per row");
+};
+
+template <int PC, int NIT>
+struct Unit {
+    float4 h[PC][NIT];
+    float4 t[NIT];
+};
+
+// transposing butterfly over a G-lane group: K values in, after log2(K) halving steps one
+// value per lane, then plain all-reduce steps down to distance 1.
+template <int K, int O>
+__device__ __forceinline__ void treduce(float (&val)[8], int gl) {
+    if constexpr (O >= 1) {
+        if constexpr (K > 1) {
+            const bool hi = (gl & O) != 0;
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) {
+                const float send = hi ? val[j] : val[j + K / 2];
+                const float keep = hi ? val[j + K / 2] : val[j];
+                val[j] = keep + xchg<O>(send);
+            }
+            treduce<K / 2, O / 2>(val, gl);
+        } else {
+            val[0] += xchg<O>(val[0]);
+            treduce<1, O / 2>(val, gl);
+        }
+    }
+}
+
+template <int V, int M, int D>
+__global__ void __launch_bounds__(kBlock)
+k_step_fused_pipe(Dims d, RisVecParams P, StepArgs A, int n_groups_total) {
+    using S = PipeShape<V, M>;
+    constexpr int VP = S::VP, EPW = S::EPW, NP = S::NP, G = S::G, NIT = S::NIT, VPP = S::VPP;
+    constexpr int PC = S::PC, CHUNKS = S::CHUNKS, UPG = S::UPG, K = S::K;
+    static_assert(D <= UPG && UPG % D == 0, "ring depth must divide the units of a group");
+    __shared__ float s_img[kBlock / kWave][kWave * 2];
+
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int gl = lane % G, gv = lane / G;
+    // wave-uniform by construction; tell the compiler so group indices live in SGPRs
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    const int nw = gridDim.x * (kBlock / kWave);
+    const float4* __restrict__ h4 = reinterpret_cast<const float4*>(A.h_r);
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(A.theta);
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(A.b);
+    const int e_last = d.E - 1;
+    const unsigned lane_off = (unsigned)(gv * NP + gl);      // lane's float4 offset inside an env's h_r block
+
+    float4 bq[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = gl + it * G;
+        bq[it] = p < NP ? b4[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    using U = Unit<PC, NIT>;
+    U ring[D];
+
+    auto load_unit = [&](U& u, int grp, int ui) {
+        const int i = ui / CHUNKS, c = ui % CHUNKS;
+        int e = grp * EPW + i;
+        e = e < e_last ? e : e_last;                       // tail: re-read the last env, masked later
+        // wave-uniform 64-bit base (SGPRs) + 32-bit lane offset + compile-time constant:
+        // the address arithmetic stays off the vector ALU
+        const float4* __restrict__ hb = h4 + (long long)e * (V * NP);
+        const float4* __restrict__ tb = t4 + (long long)e * NP;
+#pragma unroll
+        for (int pc = 0; pc < PC; ++pc) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int p = gl + it * G;
+                u.h[pc][it] = (NP % G == 0 || p < NP) ? hb[lane_off + ((c * PC + pc) * VPP * NP + it * G)]
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (c == 0) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int p = gl + it * G;
+                u.t[it] = (NP % G == 0 || p < NP) ? tb[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    int grp = wid;
+    if (grp >= n_groups_total) return;                     // whole wave: no cross-lane op is skipped
+#pragma unroll
+    for (int ui = 0; ui < D; ++ui) load_unit(ring[ui], grp, ui);
+    const int v_mine = lane % VP;
+
+    // One group: consume its UPG units (refilling the ring D units ahead, across the group
+    // boundary), prefetch the NEXT group's step() inputs into `in_nx`, then run step() with
+    // `in`.  Called alternately with (inA, inB) / (inB, inA) so no register copy - and hence
+    // no wait on the prefetch - is needed at the loop boundary.
+    auto do_group = [&](int g_cur, const StepIn& in, StepIn& in_nx) {
+        // The prefetch is unconditional (straight-line code keeps the compiler's vmcnt
+        // bookkeeping exact): a wave on its last group re-reads that group's first D units.
+        const int nxt = (g_cur + nw < n_groups_total) ? g_cur + nw : g_cur;
+        const int e_mine = g_cur * EPW + lane / VP;
+        const bool active = e_mine < d.E;
+        // Take the wait for this group's step() inputs HERE (they were requested a whole
+        // step() ago), not at their first use inside step(), where the compiler could only
+        // express it as vmcnt(0) and would drain the next group's prefetch with it.
+        asm volatile("" ::"v"(in.a0), "v"(in.a1), "v"(in.B), "v"(in.Q0), "v"(in.pl), "v"(in.part), "v"(in.G));
+
+        float2 w0[NIT], w1[NIT];
+#pragma unroll
+        for (int ui = 0; ui < UPG; ++ui) {
+            U& u = ring[ui % D];
+            const int i = ui / CHUNKS, c = ui % CHUNKS;
+            if (c == 0) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    w0[it] = cmul(make_float2(u.t[it].x, u.t[it].y), make_float2(bq[it].x, bq[it].y));
+                    w1[it] = cmul(make_float2(u.t[it].z, u.t[it].w), make_float2(bq[it].z, bq[it].w));
+                }
+            }
+            float val[8];
+#pragma unroll
+            for (int pc = 0; pc < PC; ++pc) {
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    acc = cfma(make_float2(u.h[pc][it].x, u.h[pc][it].y), w0[it], acc);
+                    acc = cfma(make_float2(u.h[pc][it].z, u.h[pc][it].w), w1[it], acc);
+                }
+                val[2 * pc] = acc.x;
+                val[2 * pc + 1] = acc.y;
+            }
+            treduce<K, G / 2>(val, gl);
+            if (gl % S::WSTRIDE == 0) {
+                const int j = gl / S::WSTRIDE;                 // value index = (row-in-unit, re/im)
+                const int v = (c * PC + (j >> 1)) * VPP + gv;
+                s_img[wave][(i * VP + v) * 2 + (j & 1)] = val[0];
+            }
+            // refill the slot just consumed, D units ahead (crossing into the next group)
+            if (ui + D < UPG) load_unit(u, g_cur, ui + D);
+            else load_unit(u, nxt, ui + D - UPG);
+        }
+        // step() inputs of the next group: in flight during this group's step()
+        in_nx = load_step_in(d, A, nxt * EPW + lane / VP, v_mine, nxt * EPW + lane / VP < d.E);
+
+        // the wave's own LDS writes -> its own reads (LDS is in-order per wave; no other wave
+        // touches this slice); the barrier only pins the compiler's ordering
+        __builtin_amdgcn_wave_barrier();
+        float g = 0.f;
+        if (active) {
+            const long long idx = (long long)e_mine * V + v_mine;
+            const float2 img = *reinterpret_cast<const float2*>(&s_img[wave][lane * 2]);
+            g = gain_from_img(img, in.pl, A.h_d, idx);
+            A.gain[idx] = g;
+        }
+        step_core<VP>(d, P, A, e_mine, v_mine, active, g, in);
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    StepIn inA = load_step_in(d, A, grp * EPW + lane / VP, v_mine, grp * EPW + lane / VP < d.E), inB;
+    while (true) {
+        do_group(grp, inA, inB);
+        grp += nw;
+        if (grp >= n_groups_total) break;
+        do_group(grp, inB, inA);
+        grp += nw;
+        if (grp >= n_groups_total) break;
+    }
+}
+
+// waves per CU to launch (each strides over groups); tunable for experiments
+static int pipe_waves_per_cu() {
+    static int v = [] {
+        const char* s = std::getenv("RISVEC_PIPE_WAVES_PER_CU");
+        const int x = s ? std::atoi(s) : 0;
+        // measured on MI355X (C3, C4 shard, C5 shape): 4 waves/CU (one per SIMD, each with
+        // 4 units = 20 x 1 KiB loads in flight) beats 8 and 12; more concurrent streams cost
+        // more in DRAM locality than they return in latency hiding
+        return (x >= 1 && x <= 32) ? x : 4;
+    }();
+    return v;
+}
+
+static int num_cus() {
+    static int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+        }
+        return cus;
+    }();
+    return n;
+}
+
+template <int V, int M, int D>
+static hipError_t launch_pipe(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
+    using S = PipeShape<V, M>;
+    const int n_groups = (s.n_envs + S::EPW - 1) / S::EPW;
+    const int wpb = kBlock / kWave;
+    long long want_waves = (long long)num_cus() * pipe_waves_per_cu();
+    if (want_waves > n_groups) want_waves = n_groups;
+    const unsigned grid = (unsigned)((want_waves + wpb - 1) / wpb);
+    hipLaunchKernelGGL((k_step_fused_pipe<V, M, D>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_groups);
+    return hipGetLastError();
+}
+
+hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, const StepArgs& a,
+                                  hipStream_t st) {
+    static const bool off = std::getenv("RISVEC_NO_PIPE") != nullptr;    // A/B switch for experiments
+    if (off) return hipErrorNotSupported;
+    const int V = s.n_veh, M = s.n_ris;
+    if (V == 8 && M == 64) return launch_pipe<8, 64, 4>(s, p, a, st);
+    if (V == 8 && M == 36) return launch_pipe<8, 36, 4>(s, p, a, st);
+    if (V == 8 && M == 40) return launch_pipe<8, 40, 4>(s, p, a, st);
+    if (V == 4 && M == 16) return launch_pipe<4, 16, 4>(s, p, a, st);
+    if (V == 16 && M == 64) return launch_pipe<16, 64, 4>(s, p, a, st);
+    if (V == 16 && M == 256) return launch_pipe<16, 256, 2>(s, p, a, st);
+    return hipErrorNotSupported;
+}
+
+}  // namespace risvec

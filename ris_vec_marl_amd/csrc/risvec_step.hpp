@@ -1,0 +1,317 @@
+// step() for one (env, vehicle) lane and its helpers, shared by k_step.hip (generic
+// shapes) and k_step_pipe.hip (software-pipelined kernels for compile-time shapes).
+//
+// Reference: Simulation-MARL-BCD/Environment.py (ENV): compute_data_rate ENV:331-372,
+// step ENV:547-731; observation marl_train_bcd.py:819-827, action map :1601-1608.
+#pragma once
+
+#include "risvec_launch.hpp"
+
+namespace risvec {
+
+struct StepArgs {
+    const float* action;
+    const int32_t* partner;
+    const int32_t* n_groups;
+    const int32_t* arrivals;
+    const float* pl;
+    const float* h_r;
+    const float* theta;
+    const float* b;
+    const float* h_d;
+    float* gain;
+    float* data_buf;
+    float* mec_q;
+    float* rate;
+    float* data_t;
+    float* data_p;
+    float* reward;
+    float* over_power;
+    float* obs;
+    float* metrics;
+    float* power_w;
+    uint64_t seed;
+    uint32_t counter;
+    uint32_t flags;
+};
+
+// ---------------------------------------------------------------------------
+// cross-lane exchange with a partner lane "O away".  O = 1, 2 are quad permutes,
+// O = 4 / 8 use the DPP mirrors (partner = lane^7 / lane^15: it differs in bit 2 / bit 3,
+// which is all a butterfly needs when steps run in monotone order), O = 16 is a
+// ds_swizzle inside 32 lanes, O = 32 a bpermute.  DPP forms are plain VALU: no LDS
+// crossbar round trip.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+
+template <int O>
+__device__ __forceinline__ float xchg(float x) {
+    if constexpr (O == 1) return dpp_mov<0xB1>(x);          // quad_perm [1,0,3,2]
+    else if constexpr (O == 2) return dpp_mov<0x4E>(x);     // quad_perm [2,3,0,1]
+    else if constexpr (O == 4) return dpp_mov<0x141>(x);    // row_half_mirror
+    else if constexpr (O == 8) return dpp_mov<0x140>(x);    // row_mirror
+    else if constexpr (O == 16)
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
+    else return __shfl_xor(x, 32, kWave);
+}
+
+// all-reduce (sum) over aligned groups of W lanes, ascending butterfly
+template <int W>
+__device__ __forceinline__ float gsum(float x) {
+    if constexpr (W >= 2) x += xchg<1>(x);
+    if constexpr (W >= 4) x += xchg<2>(x);
+    if constexpr (W >= 8) x += xchg<4>(x);
+    if constexpr (W >= 16) x += xchg<8>(x);
+    if constexpr (W >= 32) x += xchg<16>(x);
+    if constexpr (W >= 64) x += xchg<32>(x);
+    return x;
+}
+
+// a / b as a * rcp(b): v_rcp_f32 is 1 ulp, the product adds 0.5 -> <= 1.5 ulp (1e-7), two
+// instructions instead of the ~11 of an IEEE-rounded division.  Every denominator on this
+// path is a normal float well inside rcp's range (noise power ~1e-14 ... cycles ~1e9).
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
+// log2(1 + x) for x >= 0, relative error < 1e-6: below 1/16 the 1+x rounding would eat the
+// result, so a 5-term log1p series is used there; above it v_log_f32(1 + x).
+__device__ __forceinline__ float log2_1p(float x) {
+    const float big = __builtin_amdgcn_logf(1.0f + x);
+    const float ser = x * (1.f + x * (-0.5f + x * (0.33333334f + x * (-0.25f + x * 0.2f))));
+    return x < 0.0625f ? ser * 1.4426950408889634f : big;
+}
+
+// inputs of step() for one lane, loadable ahead of the compute
+struct StepIn {
+    float a0, a1, B, Q0, pl;
+    int part, G;
+};
+
+__device__ __forceinline__ StepIn load_step_in(const Dims& d, const StepArgs& A, int e, int v, bool active) {
+    StepIn in{0.f, 0.f, 0.f, 0.f, 0.f, RISVEC_PARTNER_NONE, 1};
+    if (active) {
+        const int V = d.V;
+        const long long idx = (long long)e * V + v;
+        if (A.flags & RISVEC_STEP_POLICY_ACTION) {
+            const float2 pa = *reinterpret_cast<const float2*>(A.action + idx * 2);
+            in.a0 = pa.x;
+            in.a1 = pa.y;
+        } else {
+            in.a0 = A.action[(long long)e * 2 * V + v];
+            in.a1 = A.action[(long long)e * 2 * V + V + v];
+        }
+        in.B = A.data_buf[idx];
+        in.part = A.partner[idx];
+        in.G = A.n_groups[e];
+        in.Q0 = A.mec_q[e];
+        in.pl = A.pl ? A.pl[idx] : 0.f;
+    }
+    return in;
+}
+
+// compute_data_rate (ENV:331-372) for one lane; all lanes of the VP-group must call.
+// near = u1 if gain1 > gain2 else u2 (ENV:355-360): a vehicle listed second is "near" on ties.
+template <int VP>
+__device__ __forceinline__ float noma_rate(const RisVecParams& P, float pw0, float gain, int part, int G) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int base = lane & ~(VP - 1);
+    const bool pair = part >= 0, single = part == RISVEC_PARTNER_SINGLE;
+    const bool second = part >= RISVEC_PARTNER_SECOND;
+    const int src = base + (pair ? (part & (VP - 1)) : (lane - base));
+    const float g_p = __shfl(gain, src, kWave);
+    const float pw_p = __shfl(pw0, src, kWave);
+    const bool near = second ? !(g_p > gain) : (gain > g_p);
+    const float sig = pw0 * gain;                                            // ENV:347, 362, 367
+    const float den = (pair && !near) ? (pw_p * gain + P.noise_power) : P.noise_power;   // ENV:363-364
+    const float sinr = fdiv(sig, den);
+    const float frac = __builtin_amdgcn_rcpf((float)max(1, G));              // ENV:341-342
+    const float rate = frac * log2_1p(sinr);
+    return (pair || single) ? rate : 0.f;
+}
+
+// gain from the reduced cascade sum: | sqrt(pl) img + h_d |^2  (ENV:270-272; h_d = 0 there)
+__device__ __forceinline__ float gain_from_img(float2 img, float pl, const float* h_d, long long idx) {
+    if (h_d) {
+        const float a = sqrtf(pl);
+        const float2 hd = *reinterpret_cast<const float2*>(h_d + idx * 2);
+        const float re = fmaf(a, img.x, hd.x), im = fmaf(a, img.y, hd.y);
+        return re * re + im * im;
+    }
+    return pl * (img.x * img.x + img.y * img.y);
+}
+
+// ---------------------------------------------------------------------------
+// step() for one (env, vehicle) lane.  Called by ALL 64 lanes (cross-lane ops inside);
+// `active` masks lanes beyond V or E.
+// ---------------------------------------------------------------------------
+template <int VP>
+__device__ __forceinline__ void step_core(const Dims& d, const RisVecParams& P, const StepArgs& A,
+                                          int e, int v, bool active, float gain, const StepIn& in) {
+    const int V = d.V;
+    const long long idx = (long long)e * V + v;
+    const float eps = 1e-12f;
+    const float B = in.B, Q0 = in.Q0;
+    const int part = in.part, G = in.G;
+    float a0 = in.a0, a1 = in.a1;
+
+    // ENV:574-577
+    float fl = P.cpu_share_floor;
+    if (!isfinite(fl)) fl = 0.10f;
+    fl = fmaxf(0.f, fminf(fl, 0.95f));
+    if (A.flags & RISVEC_STEP_POLICY_ACTION) {
+        // marl_train_bcd.py:1601-1608: [-1,1] -> [0,1], CPU share floored
+        a0 = (fminf(fmaxf(a0, -0.999f), 0.999f) + 1.f) * 0.5f;
+        a1 = fmaxf((fminf(fmaxf(a1, -0.999f), 0.999f) + 1.f) * 0.5f, fl);
+    }
+
+    // (1) power projection, ENV:555-561
+    float c0 = fmaxf(a0, 0.f) * P.power_scale;
+    float c1 = fmaxf(a1, 0.f) * P.power_scale;
+    const float s = c0 + c1;
+    if (s > 1.f) {
+        const float inv = __builtin_amdgcn_rcpf(s + 1e-12f);
+        c0 = c0 * inv;
+        c1 = c1 * inv;
+    }
+    const float pw0 = c0 * P.p_max, pw1 = c1 * P.p_max;
+
+    // (2) rate, ENV:331-372
+    const float rate = noma_rate<VP>(P, pw0, gain, part, G);
+    const float tf = P.time_fast, bw = P.bandwidth_mhz;
+    const float data_t = rate * tf * bw * 1000.0f;                          // ENV:570
+
+    // (3) cpu share, ENV:572-580
+    const float cpu = fmaxf(fminf(fmaxf(a1, 0.f), 1.f), fl);
+    const float f = cpu * P.f_local_max;
+    const float Cpb = P.cycles_per_bit;
+
+    // (4) local processing, ENV:585-592
+    // When the CPU can clear the whole backlog, data_p = bc / (Cpb*1000) equals B up to
+    // rounding (1e-16 in the float64 reference).  In float32 that rounding (1e-7 B) would
+    // leak into `rem`, `off` and t_tx = off / throughput, so the identity is used directly.
+    const float bc = B * 1000.0f * Cpb;
+    const float cap = f * tf;
+    const bool clears = cap >= bc;
+    const float used = clears ? bc : cap;
+    const float data_p = clears ? B : fdiv(cap, Cpb * 1000.0f);
+
+    // (5) offload, ENV:595-601
+    const float rem = fmaxf(0.f, B - data_p);
+    const float off = fminf(data_t, rem);
+    const float thr = rate * bw * 1000.0f;
+    const float t_tx = fdiv(off, thr + 1e-12f);
+
+    // (6) MEC queue, ENV:604-610
+    const float ein = off * 1000.0f * Cpb;
+    const float ein_sum = gsum<VP>(active ? ein : 0.f);
+    float Q = Q0 + ein_sum;
+    const float edge_cap = P.f_edge_max * tf;
+    const float svc = fminf(edge_cap, Q);
+    Q -= svc;
+
+    // (7) backlog, ENV:617-618
+    float Bn = fmaxf(0.f, B - (data_p + off));
+
+    // (8) delays, ENV:622-633
+    const float inv_fe = __builtin_amdgcn_rcpf(P.f_edge_max + eps);
+    const float d_loc = fdiv(fmaxf(0.f, bc - ein), f + eps);
+    const float share = fdiv(ein, ein_sum + eps);
+    const float d_q = share * (Q0 * inv_fe);
+    const float d_c = ein * inv_fe;
+    const float delay = d_loc + t_tx + d_q + d_c;
+
+    // (9) energy, ENV:659-666
+    const float E_tx = pw0 * t_tx;
+    const float E_loc = P.k_cpu * (f * f) * used;
+    const float energy = E_tx + E_loc;
+
+    // (10) QoS, ENV:669-677
+    const bool viol = P.qos_enable && ((rate < P.r_min_bpshz) || (delay > P.d_max_s));
+    const float pen = viol ? P.qos_penalty : 0.f;
+
+    // (11) reward, ENV:696-703
+    const float cost = P.w_d * delay + P.w_e * energy;
+    const float rew = fminf(fmaxf(-cost - pen, -P.reward_clip), P.reward_clip);
+
+    // (12) arrivals, ENV:717-719
+    int arr = 0;
+    if (A.arrivals) {
+        if (active) arr = A.arrivals[idx];
+    } else {
+        const uint4 r = philox4x32_10((uint32_t)(d.env_offset + e), (uint32_t)v, A.counter,
+                                      kSiteArrivals, A.seed);
+        arr = poisson_from_u(u01(r.x), P.poisson_cdf);
+    }
+    Bn += (float)arr * tf * 1000.0f;
+
+    // (13) ENV:721-729
+    const float over_power = fmaxf(0.f, (pw0 + pw1) - P.p_max);
+    const float rew_sum = gsum<VP>(active ? rew : 0.f);
+    const float inv_v = __builtin_amdgcn_rcpf((float)V);
+
+    if (active) {
+        A.data_buf[idx] = Bn;
+        A.rate[idx] = rate;
+        A.data_t[idx] = data_t;
+        A.data_p[idx] = data_p;
+        A.reward[idx] = rew;
+        A.over_power[idx] = over_power;
+        if (A.flags & RISVEC_STEP_OBS) {
+            // marl_train_bcd.py:819-827 (element 3 = over_data/10 is always 0)
+            float* o = A.obs + idx * 5;
+            o[0] = Bn * 0.1f; o[1] = data_t * 0.1f; o[2] = data_p * 0.1f; o[3] = 0.f; o[4] = rate * 0.05f;
+        }
+        if (A.flags & RISVEC_STEP_POWER_W) {
+            const float inv_tf = __builtin_amdgcn_rcpf(tf);
+            A.power_w[(long long)e * 2 * V + v] = E_tx * inv_tf;
+            A.power_w[(long long)e * 2 * V + V + v] = E_loc * inv_tf;
+        }
+        if (v == 0) A.mec_q[e] = Q;
+    }
+
+    if (A.flags & RISVEC_STEP_METRICS) {
+        const float z = 0.f;
+        const float s_off = gsum<VP>(active ? off : z);
+        const float s_dp = gsum<VP>(active ? data_p : z);
+        const float s_b = gsum<VP>(active ? B : z);
+        const float s_dl = gsum<VP>(active ? d_loc : z);
+        const float s_dq = gsum<VP>(active ? d_q : z);
+        const float s_dc = gsum<VP>(active ? d_c : z);
+        const float s_tx = gsum<VP>(active ? t_tx : z);
+        const float s_ut = gsum<VP>(active ? fdiv(used, cap + 1e-12f) : z);
+        const float s_vi = gsum<VP>(active && viol ? 1.f : z);
+        const float s_de = gsum<VP>(active ? delay : z);
+        const float s_en = gsum<VP>(active ? energy : z);
+        if (active && v == 0) {
+            float4* m = reinterpret_cast<float4*>(A.metrics + (long long)e * RISVEC_METRICS);
+            m[0] = make_float4(rew_sum * inv_v, s_off, s_dp, Q);
+            m[1] = make_float4(s_b * inv_v, s_dl * inv_v, s_dq * inv_v, s_dc * inv_v);
+            m[2] = make_float4(s_tx * inv_v, fdiv(svc, edge_cap + 1e-12f), s_ut * inv_v, s_vi * inv_v);
+            m[3] = make_float4(s_de * inv_v, s_en * inv_v, 0.f, 0.f);
+        }
+    } else if (active && v == 0) {
+        A.metrics[(long long)e * RISVEC_METRICS] = rew_sum * inv_v;          // global_reward only
+    }
+}
+
+inline StepArgs make_step_args(const RisVecState& s, const float* action, const int32_t* partner,
+                               const int32_t* n_groups, const int32_t* arrivals, uint64_t seed,
+                               uint32_t counter, uint32_t flags) {
+    StepArgs a;
+    a.action = action; a.partner = partner; a.n_groups = n_groups; a.arrivals = arrivals;
+    a.pl = s.pl; a.h_r = s.h_r; a.theta = s.theta; a.b = s.b; a.h_d = s.h_d;
+    a.gain = s.gain; a.data_buf = s.data_buf; a.mec_q = s.mec_q;
+    a.rate = s.rate; a.data_t = s.data_t; a.data_p = s.data_p; a.reward = s.reward;
+    a.over_power = s.over_power; a.obs = s.obs; a.metrics = s.metrics; a.power_w = s.power_w;
+    a.seed = seed; a.counter = counter; a.flags = flags;
+    return a;
+}
+
+// specialised software-pipelined fused kernels (k_step_pipe.hip); returns
+// hipErrorNotSupported when the shape has no specialisation.
+hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, const StepArgs& a,
+                                  hipStream_t st);
+
+}  // namespace risvec
