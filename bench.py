@@ -8,8 +8,9 @@ One "step" = one launch of the fused north-star kernel (RIS cascaded gains + ste
 `Environ.step()` with its channel gains recomputed from h_r and theta ("everything
 every step" mode of SURVEY 8d).  Workload at N=1: BASELINE.json configs[2]
 (32 768 envs x 8 vehicles x 64 RIS elements, fp32/complex64, synthetic channel draws);
-N>1: the same per GPU (weak scaling), env ids sharded by rank, plus the joint-observation
-all-gather for the global critic on a side stream.
+N>1: the same per GPU (weak scaling), env ids sharded by rank with no data-path
+collective; the north-star's joint-observation all-gather for the global critic runs on
+a side stream every `--gather-every` steps.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and
 `cpu_baseline`.
@@ -32,11 +33,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes(V: int, M: int) -> int:
-    """bytes one env-step must move in fused mode (fp32 / complex64):
-    reads h_r 8VM + theta 8M + action 8V + DataBuf 4V + path-loss 4V + partner 4V + n_groups 4
-    + Q 4; writes gain 4V + DataBuf 4V + reward 4V + rate/data_t/data_p 12V + obs 20V + Q 4 +
-    metrics 56."""
+def algorithmic_bytes(V: int, M: int, mode: str = "fused") -> int:
+    """bytes one env-step must move (fp32 / complex64).
+    fused : reads h_r 8VM + theta 8M + action 8V + DataBuf 4V + path-loss 4V + partner 4V +
+            n_groups 4 + Q 4; writes gain 4V + DataBuf 4V + reward 4V + rate/data_t/data_p 12V +
+            obs 20V + Q 4 + metrics 56                               = 8VM + 8M + 64V + 68
+    cached: the same without h_r/theta and with the gain read instead of written = 60V + 68
+    bcd   : fused + theta written back (h_r counted once: the sweep and the gain pass are
+            separate kernels, so real traffic is ~2x h_r)            = 8VM + 16M + 64V + 68"""
+    if mode == "cached":
+        return 60 * V + 68
+    if mode == "bcd":
+        return 8 * V * M + 16 * M + 64 * V + 68
     return 8 * V * M + 8 * M + 64 * V + 68
 
 
@@ -120,6 +128,28 @@ def cpu_baseline(V: int, M: int, budget_s: float = 12.0) -> dict:
                 single_env_value=1.0 / ts, host_cores=os.cpu_count())
 
 
+def measured_traffic(kernel_prefix: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_summary.json, written by tools/summarize_pmc.py from separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command): FETCH_SIZE x 2 (gfx950 counts a wide
+    coalesced stream at half its bytes, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        names = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_summary.json"))
+    except OSError:
+        return None, None
+    for name in names:                                   # the latest round wins
+        try:
+            d = json.load(open(os.path.join(pdir, name)))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if kernel_prefix in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                best = ((2.0 * v["FETCH_SIZE"]["mean_kib"] + v["WRITE_SIZE"]["mean_kib"]) * 1024.0, name)
+    return best if best else (None, None)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,8 +158,10 @@ def main() -> None:
     ap.add_argument("--envs-per-gpu", type=int, default=32768)
     ap.add_argument("--veh", type=int, default=8)
     ap.add_argument("--ris", type=int, default=64)
-    ap.add_argument("--gather-every", type=int, default=1,
-                    help="N>1: all-gather the joint observation every k steps (0 = never)")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N>1: all-gather the joint observation every k steps on a side stream (0 = never). "
+                         "At 32 768 envs/GPU one gather moves 5.2 MB per rank over point-to-point xGMI links, "
+                         "several env steps' worth of time, so it is amortised rather than issued every step.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lean", action="store_true", help="experiment: skip metrics and obs writes")
     ap.add_argument("--mode", default="fused", choices=["fused", "cached", "bcd"],
@@ -162,17 +194,20 @@ def main() -> None:
         try:
             gather = rdist.JointObsGather(E, V, device)
             gather.start(env.tensors["obs"]); gather.wait()
-            gather_note = "joint obs [E_local,5V] fp32 all-gather (RCCL) every %d step(s), side stream, double-buffered" % args.gather_every
+            gather_note = ("joint obs [E_local,5V] fp32 all-gather (RCCL over xGMI) every %d step(s), side stream, "
+                           "staged + double-buffered" % args.gather_every)
         except Exception as ex:           # keep the env path measurable even if RCCL is unavailable
             gather = None
             gather_note = "disabled: %r" % (ex,)
+    elif world > 1:
+        gather_note = "off (--gather-every 0)"
 
     fused, bcd = args.mode != "cached", args.mode == "bcd"
+    full = not args.lean
 
     def one_step(i: int) -> None:
-        env.step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=not args.lean, power_w=False, obs=not args.lean)
+        env.step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full, power_w=False, obs=full)
         if gather is not None and i % args.gather_every == 0:
-            gather.wait()
             gather.start(env.tensors["obs"])
 
     for i in range(args.warmup):
@@ -198,16 +233,21 @@ def main() -> None:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    # average device time per launch on the launch stream (events bracket the K launches,
-    # so inter-launch gaps are included: slightly pessimistic)
+    # average device time per launch on the launch stream (HIP events bracket the K launches
+    # on the stream they are issued on, so inter-launch gaps are included: slightly pessimistic)
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
 
     if rank != 0:
         return
-    per_env = {"fused": algorithmic_bytes(V, M), "cached": 60 * V + 68,
-               "bcd": 8 * V * M + 16 * M + 64 * V + 68}[args.mode]
+    per_env = algorithmic_bytes(V, M, args.mode)
     bytes_per_launch = per_env * E
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    kname = {"fused": "k_step_fused", "cached": "k_step<", "bcd": "k_bcd"}[args.mode]
+    traffic, traffic_src = (None, None)
+    if (E, V, M, args.mode) == (32768, 8, 64, "fused") and full:
+        traffic, traffic_src = measured_traffic(kname)
+    workload = {"fused": "RIS cascaded gains + step()", "cached": "step() on cached gains",
+                "bcd": "BCD sweep + gains + step()"}[args.mode]
     out = {
         "metric": "env-steps/sec (all agents) at 8 veh x 64 RIS",
         "value": E * world * args.steps / dt,
@@ -221,18 +261,20 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: %d parallel envs/GPU x %d vehicles x %d RIS elements, fp32/complex64, "
-                               "%s every step, metrics+obs written, Philox arrivals" % (E, V, M,
-                               {"fused": "RIS cascaded gains + step()", "cached": "step() on cached gains",
-                                "bcd": "BCD sweep + gains + step()"}[args.mode]),
+        "config": {"workload": "BASELINE configs[%d]: %d parallel envs/GPU x %d vehicles x %d RIS elements, "
+                               "fp32/complex64, %s every step, metrics+obs %s, Philox arrivals"
+                               % (4 if bcd else 2, E, V, M, workload, "written" if full else "off"),
                    "envs_per_gpu": E, "n_veh": V, "n_ris": M, "mode": args.mode, "allgather": gather_note,
                    "agent_steps_per_s": E * world * args.steps / dt * V},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": {"fused": "k_step_fused", "cached": "k_step", "bcd": "k_bcd+k_step_fused"}[args.mode],
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": {"fused": "k_step_fused_pipe<8,64,4>" if (V, M) == (8, 64) else "k_step_fused*",
+                                "cached": "k_step", "bcd": "k_bcd_lane + k_step_fused*"}[args.mode],
                      "algorithmic_bytes_per_env_step": per_env, "bytes_per_launch": bytes_per_launch,
                      "avg_launch_ms": kernel_ms},
     }
+    if bcd:
+        out["config"]["bcd_candidate_evals_per_s"] = E * world * args.steps / dt * M * 8
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(V, M)
     elif world > 1:

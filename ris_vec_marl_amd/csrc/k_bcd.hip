@@ -4,23 +4,207 @@
 // optimize_compute_objective_function ENV:222-231.  The reference objective sums
 // the WHOLE [V,M] product (ENV:226 has no vehicle index), so it equals
 //     Kc * | sum_m theta_m c_m |^2,   c_m = (sum_v h_r[v,m]) b[m],   Kc > 0,
-// and the arg-max over the 2^b candidates for element m is that of
-// | S - theta_m c_m + cand c_m |^2.  That turns the reference's O(M^2 2^b V^2) sweep
-// into O(V M + M 2^b).  The sweep is a chain of M dependent discrete decisions, so
-// it runs in float64 (inputs h_r, theta, b are the float32 tensors): a float32 sweep
-// would flip near-tied decisions and drift away from the reference's theta.
+// and for element m the candidate score is Kc |rest + cand_k c_m|^2 with
+// rest = S - theta_m c_m.  Since
+//     |rest + cand c|^2 = |rest|^2 + |c|^2 + 2 Re(cand * conj(rest) c),
+// the arg-max over the 2^b candidates is the arg-max of Re(cand_k q), q = conj(rest) c_m:
+// two FMAs per candidate.  That turns the reference's O(M^2 2^b V^2) sweep into
+// O(V M + M 2^b).  `best < x` from best = 0 (ENV:210-218) = "first index wins ties, and the
+// winner must score > 0", i.e. the new S = rest + cand c must be non-zero; otherwise the
+// element becomes the integer 0 (ENV:211, 220).
 //
-// Mapping: a group of NC = 2^b lanes owns one env, lane k evaluates candidate k; the
-// arg-max (first index wins ties, and the winner must score > 0: ENV:210-218) is a
-// group butterfly.  c[] and theta[] of the envs of a block are staged in LDS.
-#include "risvec_launch.hpp"
+// The sweep is a chain of M dependent discrete decisions, so it runs in float64 (inputs h_r,
+// theta, b are the float32 tensors): a float32 sweep would flip near-tied decisions and
+// drift away from the reference's theta.
+//
+// k_bcd_lane (even M): a 256-thread block stages c[] (f64) and theta[] of `epb` envs in
+// LDS - phase 1 streams h_r with 16-byte loads, two lanes per element pair splitting the
+// vehicle rows - then ONE LANE PER ENV walks the chain with no cross-lane traffic, and the
+// block writes theta back coalesced.  LDS capacity (24 B per element per env) bounds the
+// envs in flight per CU, so two blocks per CU alternate streaming and sweeping.
+// k_bcd_group (any M): the earlier form, 2^b lanes per env with a butterfly arg-max.
+#include "risvec_step.hpp"
 
 namespace risvec {
 
+constexpr int kBcdLdsBudget = 79 * 1024;        // dynamic LDS per block; with the static candidate
+                                                // table two blocks fit a CU's 160 KiB
+
+__host__ __device__ constexpr size_t bcd_env_bytes(int M) {
+    return (size_t)(M + 1) * sizeof(double2) + (size_t)(M + 2) * sizeof(float2);
+}
+
+// arg-max_k Re(cand_k q) over the NC = 2^b unit phasors cand_k = exp(j 2 pi k / NC); the
+// first index wins exact ties.  Returns k and writes the phasor.  Branch-free for NC = 8.
+template <int NC>
+__device__ __forceinline__ int pick_candidate(double qr, double qi, const double2* __restrict__ cand,
+                                              double& nr, double& ni) {
+    if constexpr (NC == 8) {
+        // Re(cand_k q) = cand_k . w with w = (qr, -qi): the winner is the multiple of 45 deg
+        // nearest to the direction of w -> an octant test instead of eight dot products.
+        // (Boundaries sit at tan(22.5 deg), irrational: exact ties only at w = 0 -> k = 0.)
+        const double fa = fabs(qr), fb = fabs(qi);
+        const double t = 0.41421356237309503;               // tan(pi/8)
+        const double r = 0.70710678118654757;               // cos(pi/4), as numpy rounds it
+        const bool ax = fb <= t * fa;                        // along +-x (also w = 0 -> k = 0)
+        const bool ay = !ax && (fa <= t * fb);               // along +-y
+        const bool xn = qr < 0.0, yn = qi > 0.0;             // signs of w = (qr, -qi)
+        const double mx = ax ? 1.0 : r, my = ay ? 1.0 : r;
+        nr = ay ? 0.0 : (xn ? -mx : mx);
+        ni = ax ? 0.0 : (yn ? -my : my);
+        const int kd = yn ? (xn ? 5 : 7) : (xn ? 3 : 1);
+        return ax ? (xn ? 4 : 0) : (ay ? (yn ? 6 : 2) : kd);
+    } else {
+        double best = cand[0].x * qr - cand[0].y * qi;
+        int kb = 0;
+        for (int k = 1; k < NC; ++k) {
+            const double dk = cand[k].x * qr - cand[k].y * qi;
+            if (dk > best) { best = dk; kb = k; }            // strict: first index wins ties
+        }
+        nr = cand[kb].x; ni = cand[kb].y;
+        return kb;
+    }
+}
+
+constexpr int kBcdRows = 8;     // h_r rows a lane keeps in flight per element pair
+
 template <int NC>
 __global__ void __launch_bounds__(kBlock)
-k_bcd(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ theta,
-      const float* __restrict__ b, int32_t* __restrict__ idx_out) {
+k_bcd_lane(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ theta,
+           const float* __restrict__ b, int32_t* __restrict__ idx_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int M = d.M, V = d.V, NPAIR = M >> 1;
+    const int cstride = M + 1;                   // +16 B: lanes (envs) land on different banks
+    const int tstride = M + 2;
+    double2* s_c = reinterpret_cast<double2*>(smem);                      // [epb][cstride]
+    float2* s_th = reinterpret_cast<float2*>(s_c + (size_t)epb * cstride); // [epb][tstride]
+    __shared__ double2 s_cand[NC];
+    const int tid = threadIdx.x;
+    const int e_blk = blockIdx.x * epb;
+    const int n_env = min(epb, d.E - e_blk);
+    const float4* __restrict__ h4 = reinterpret_cast<const float4*>(h_r);
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(theta);
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(b);
+
+    if (tid < NC) {                              // candidate k: exp(j 2 pi k / NC)  (ENV:169, 213)
+        double s, c;
+        sincospi(2.0 * (double)tid / (double)NC, &s, &c);
+        s_cand[tid] = make_double2(c, s);
+    }
+
+    // ---- phase 1: c[i][m] = (sum_v h_r[e,v,m]) b[m].  The (env, element-pair) slots of the
+    // block are flattened over the threads, two lanes per slot: lane 2s takes the even vehicle
+    // rows, lane 2s+1 the odd ones (their halves meet through one DPP exchange); each lane
+    // keeps up to kBcdRows 16-byte loads in flight.  The odd lane also stages theta.
+    const int vh = tid & 1;
+    const int n_slot = n_env * NPAIR;
+    for (int s0 = 0; s0 < n_slot; s0 += kBlock / 2) {
+        const int slot = s0 + (tid >> 1);
+        const bool in = slot < n_slot;
+        const int sl = in ? slot : 0;
+        const int i = sl / NPAIR, p = sl - i * NPAIR;
+        const long long e = e_blk + i;
+        const float4* __restrict__ he = h4 + (e * V) * NPAIR + p;
+        double s0r = 0.0, s0i = 0.0, s1r = 0.0, s1i = 0.0;
+        for (int v0 = 0; v0 < V; v0 += 2 * kBcdRows) {
+            float4 hb[kBcdRows];
+#pragma unroll
+            for (int k = 0; k < kBcdRows; ++k) {
+                // unconditional load from a clamped (always valid) row: a predicated load would
+                // become a branch with its own vmcnt(0) and serialise the eight requests
+                const int v = v0 + vh + 2 * k;
+                hb[k] = he[(long long)(v < V ? v : V - 1) * NPAIR];
+            }
+#pragma unroll
+            for (int k = 0; k < kBcdRows; ++k) {
+                const bool ok = in && (v0 + vh + 2 * k) < V;
+                s0r += ok ? (double)hb[k].x : 0.0; s0i += ok ? (double)hb[k].y : 0.0;
+                s1r += ok ? (double)hb[k].z : 0.0; s1i += ok ? (double)hb[k].w : 0.0;
+            }
+        }
+        s0r += xchg<1>(s0r); s0i += xchg<1>(s0i);
+        s1r += xchg<1>(s1r); s1i += xchg<1>(s1i);
+        if (in) {
+            if (vh == 0) {
+                const float4 bb = b4[p];
+                s_c[(size_t)i * cstride + 2 * p] = make_double2(s0r * bb.x - s0i * bb.y, s0r * bb.y + s0i * bb.x);
+                s_c[(size_t)i * cstride + 2 * p + 1] = make_double2(s1r * bb.z - s1i * bb.w, s1r * bb.w + s1i * bb.z);
+            } else {
+                const float4 t = t4[e * NPAIR + p];
+                s_th[(size_t)i * tstride + 2 * p] = make_float2(t.x, t.y);
+                s_th[(size_t)i * tstride + 2 * p + 1] = make_float2(t.z, t.w);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phases 2+3: one lane per env
+    if (tid < n_env) {
+        const double2* __restrict__ c = s_c + (size_t)tid * cstride;
+        float2* th = s_th + (size_t)tid * tstride;
+        const long long e = e_blk + tid;
+        // phase 2: S = sum_m theta_m c_m, four independent chains, fixed order (deterministic)
+        double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};
+        int m = 0;
+        for (; m + 3 < M; m += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double2 ck = c[m + k];
+                const double tr = th[m + k].x, ti = th[m + k].y;
+                ar[k] += tr * ck.x - ti * ck.y;
+                ai[k] += tr * ck.y + ti * ck.x;
+            }
+        }
+        for (; m < M; ++m) {
+            const double2 ck = c[m];
+            const double tr = th[m].x, ti = th[m].y;
+            ar[0] += tr * ck.x - ti * ck.y;
+            ai[0] += tr * ck.y + ti * ck.x;
+        }
+        double Sr = (ar[0] + ar[1]) + (ar[2] + ar[3]), Si = (ai[0] + ai[1]) + (ai[2] + ai[3]);
+
+        // phase 3: the chain
+        double2 cm = c[0];
+        float2 tm = th[0];
+        for (m = 0; m < M; ++m) {
+            // next element's operands do not depend on S: fetch them under this step's chain
+            const int mn = m + 1 < M ? m + 1 : m;
+            const double2 cn = c[mn];
+            const float2 tn = th[mn];
+            const double tr = tm.x, ti = tm.y;
+            const double rr = Sr - (tr * cm.x - ti * cm.y);
+            const double ri = Si - (tr * cm.y + ti * cm.x);
+            const double qr = rr * cm.x + ri * cm.y;            // q = conj(rest) * c_m
+            const double qi = rr * cm.y - ri * cm.x;
+            double nr, ni;
+            int kb = pick_candidate<NC>(qr, qi, s_cand, nr, ni);
+            const double nSr = rr + (nr * cm.x - ni * cm.y);
+            const double nSi = ri + (nr * cm.y + ni * cm.x);
+            const bool none = nSr == 0.0 && nSi == 0.0;         // no candidate scores above 0
+            Sr = none ? rr : nSr;
+            Si = none ? ri : nSi;
+            th[m] = make_float2(none ? 0.f : (float)nr, none ? 0.f : (float)ni);
+            if (idx_out) idx_out[e * M + m] = none ? -1 : kb;
+            cm = cn; tm = tn;
+        }
+    }
+    __syncthreads();
+
+    // ---- write theta back, coalesced
+    float2* __restrict__ th_out = reinterpret_cast<float2*>(theta);
+    for (int t = tid; t < n_env * M; t += kBlock) {
+        const int i = t / M, m = t - i * M;
+        th_out[(long long)(e_blk + i) * M + m] = s_th[(size_t)i * tstride + m];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// generic form (any M): 2^b lanes per env, butterfly arg-max
+// ---------------------------------------------------------------------------
+template <int NC>
+__global__ void __launch_bounds__(kBlock)
+k_bcd_group(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ theta,
+            const float* __restrict__ b, int32_t* __restrict__ idx_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = d.M, V = d.V;
     double2* s_c = reinterpret_cast<double2*>(smem);                 // [epb][M]
@@ -28,7 +212,6 @@ k_bcd(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ theta,
     const int e_blk = blockIdx.x * epb;
     const int n_env = min(epb, d.E - e_blk);
 
-    // phase 1: c[i][m] = (sum_v h_r[e,v,m]) * b[m]; stage theta
     for (int t = threadIdx.x; t < n_env * M; t += kBlock) {
         const int i = t / M, m = t % M;
         const long long e = e_blk + i;
@@ -52,7 +235,6 @@ k_bcd(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ theta,
     const float2* th = s_th + (size_t)gi * M;
     const long long e = e_blk + gi;
 
-    // phase 2: S = sum_m theta_m c_m
     double Sr = 0.0, Si = 0.0;
     if (has_env) {
         for (int m = k; m < M; m += NC) {
@@ -65,21 +247,17 @@ k_bcd(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ theta,
     Sr = group_sum<NC>(Sr);
     Si = group_sum<NC>(Si);
 
-    // candidate k: exp(j 2 pi k / NC)   (ENV:169, 213)
     double cs, cc;
     sincospi(2.0 * (double)k / (double)NC, &cs, &cc);
     const int lane = threadIdx.x & (kWave - 1);
     const int base = lane - k;
 
-    // phase 3: the sweep
     for (int m = 0; m < M; ++m) {
         const double2 cm = c[m];
         const double tr = th[m].x, ti = th[m].y;
         const double rr = Sr - (tr * cm.x - ti * cm.y);
         const double ri = Si - (tr * cm.y + ti * cm.x);
-        const double pr = cc * cm.x - cs * cm.y, pi = cc * cm.y + cs * cm.x;   // cand * c_m
-        const double zr = rr + pr, zi = ri + pi;
-        double x = zr * zr + zi * zi;
+        double x = cc * (rr * cm.x + ri * cm.y) - cs * (rr * cm.y - ri * cm.x);   // Re(cand conj(rest) c)
         int kb = k;
 #pragma unroll
         for (int o = NC / 2; o > 0; o >>= 1) {
@@ -87,11 +265,11 @@ k_bcd(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ theta,
             const int ko = __shfl_xor(kb, o, kWave);
             if (xo > x || (xo == x && ko < kb)) { x = xo; kb = ko; }
         }
-        const bool any = x > 0.0;                               // `best < x` from best = 0
         double nr = __shfl(cc, base + kb, kWave), ni = __shfl(cs, base + kb, kWave);
-        if (!any) { nr = 0.0; ni = 0.0; kb = -1; }              // integer 0, ENV:211, 220
-        Sr = rr + (nr * cm.x - ni * cm.y);
-        Si = ri + (nr * cm.y + ni * cm.x);
+        double nSr = rr + (nr * cm.x - ni * cm.y);
+        double nSi = ri + (nr * cm.y + ni * cm.x);
+        if (nSr == 0.0 && nSi == 0.0) { nr = 0.0; ni = 0.0; kb = -1; nSr = rr; nSi = ri; }
+        Sr = nSr; Si = nSi;
         if (has_env && k == 0) {
             reinterpret_cast<float2*>(theta)[e * M + m] = make_float2((float)nr, (float)ni);
             if (idx_out) idx_out[e * M + m] = kb;
@@ -102,13 +280,32 @@ k_bcd(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ theta,
 template <int NC>
 static hipError_t launch_bcd_nc(const RisVecState& s, int32_t* idx_out, hipStream_t st) {
     const int M = s.n_ris;
+    if ((M & 1) == 0) {
+        const size_t per_env = bcd_env_bytes(M);
+        int epb = (int)(kBcdLdsBudget / per_env);
+        if (epb > kWave) epb = kWave;                       // one sweep lane per env, one wave of them
+        if (epb >= 1) {
+            static bool attr_set = false;                   // per instantiation
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bcd_lane<NC>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBcdLdsBudget);
+                if (e != hipSuccess) return e;
+                attr_set = true;
+            }
+            // spread envs evenly over the blocks actually needed
+            const unsigned grid = (unsigned)((s.n_envs + epb - 1) / epb);
+            hipLaunchKernelGGL((k_bcd_lane<NC>), dim3(grid), dim3(kBlock), epb * per_env, st, dims_of(s), epb,
+                               s.h_r, s.theta, s.b, idx_out);
+            return hipGetLastError();
+        }
+    }
     const size_t per_env = (size_t)M * (sizeof(double2) + sizeof(float2));
     int epb = kBlock / NC;
     const int cap = (int)((64u * 1024u) / per_env);
     if (epb > cap) epb = cap;
-    if (epb < 1) return hipErrorInvalidValue;              // M > 2730: rejected by the API layer
+    if (epb < 1) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((s.n_envs + epb - 1) / epb);
-    hipLaunchKernelGGL((k_bcd<NC>), dim3(grid), dim3(kBlock), epb * per_env, st, dims_of(s), epb,
+    hipLaunchKernelGGL((k_bcd_group<NC>), dim3(grid), dim3(kBlock), epb * per_env, st, dims_of(s), epb,
                        s.h_r, s.theta, s.b, idx_out);
     return hipGetLastError();
 }
@@ -126,8 +323,7 @@ hipError_t launch_bcd(const RisVecState& s, const RisVecParams&, int32_t* idx_ou
     }
 }
 
-// BCD + gains + step.  Round 1: two launches on the same stream (sweep, then the fused
-// gain+step kernel); a single-launch variant with h_r resident in LDS is planned.
+// BCD + gains + step: the sweep, then the fused gain+step kernel on the same stream.
 hipError_t launch_step_fused_bcd(const RisVecState& s, const RisVecParams& p, const float* action,
                                  const int32_t* partner, const int32_t* n_groups,
                                  const int32_t* arrivals, uint64_t seed, uint32_t counter,

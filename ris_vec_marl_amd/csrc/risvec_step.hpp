@@ -58,6 +58,25 @@ __device__ __forceinline__ float xchg(float x) {
     else return __shfl_xor(x, 32, kWave);
 }
 
+// float64 exchange: two 32-bit exchanges
+template <int O>
+__device__ __forceinline__ double xchg(double x) {
+    const float lo = xchg<O>(__builtin_bit_cast(float, __double2loint(x)));
+    const float hi = xchg<O>(__builtin_bit_cast(float, __double2hiint(x)));
+    return __hiloint2double(__builtin_bit_cast(int, hi), __builtin_bit_cast(int, lo));
+}
+
+template <int W>
+__device__ __forceinline__ double gsum(double x) {
+    if constexpr (W >= 2) x += xchg<1>(x);
+    if constexpr (W >= 4) x += xchg<2>(x);
+    if constexpr (W >= 8) x += xchg<4>(x);
+    if constexpr (W >= 16) x += xchg<8>(x);
+    if constexpr (W >= 32) x += xchg<16>(x);
+    if constexpr (W >= 64) x += xchg<32>(x);
+    return x;
+}
+
 // all-reduce (sum) over aligned groups of W lanes, ascending butterfly
 template <int W>
 __device__ __forceinline__ float gsum(float x) {

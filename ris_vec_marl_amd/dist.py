@@ -42,16 +42,23 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
 
 class JointObsGather:
     """All-gather of the per-rank observation block obs_local [E_local, V, 5] into the joint
-    observation [E_global, 5V], issued on a side stream into a double buffer so it overlaps
-    the next env step instead of sitting on its critical path (the message is ~1.3 MB per
-    rank at E=65536, V=8: latency-bound on xGMI).  Equal shard sizes are required (use an
-    E divisible by the world size)."""
+    observation [E_global, 5V] (the input a replicated global critic consumes).
+
+    The env overwrites its `obs` tensor every step, so `start()` first snapshots it into a
+    private staging buffer on the caller's stream (one 20V-byte-per-env device copy), then
+    issues the RCCL all-gather from that snapshot on a side stream into one of two output
+    buffers: the collective overlaps the following env steps instead of sitting on their
+    critical path, and nothing it reads or writes is touched by them.  `wait()` makes the
+    result visible to the caller's stream.  xGMI is point-to-point, so the gather is per-link
+    bound ((N-1) x message bytes into every GPU): pick its cadence accordingly.  Equal shard
+    sizes are required (use an E divisible by the world size)."""
 
     def __init__(self, n_envs_local: int, n_veh: int, device, group=None, n_buffers: int = 2):
         self.group = group
         self.world = td.get_world_size(group) if td.is_initialized() else 1
         self.device = torch.device(device)
         self.width = 5 * n_veh
+        self.stage = torch.empty(n_envs_local, self.width, dtype=torch.float32, device=self.device)
         self.bufs = [torch.empty(self.world * n_envs_local, self.width, dtype=torch.float32, device=self.device)
                      for _ in range(n_buffers)]
         self.i = 0
@@ -59,21 +66,22 @@ class JointObsGather:
         self._work = None
 
     def start(self, obs_local: torch.Tensor) -> torch.Tensor:
-        """Launch the gather of `obs_local`; returns the buffer it will land in."""
+        """Snapshot `obs_local` and launch its gather; returns the buffer it will land in
+        (valid after `wait()`)."""
+        self.wait()                                   # the previous gather still reads `stage`
         out = self.bufs[self.i]
         self.i = (self.i + 1) % len(self.bufs)
         src = obs_local.reshape(obs_local.shape[0], self.width)
         if self.world == 1:
             out.copy_(src, non_blocking=True)
-            self._work = None
             return out
+        self.stage.copy_(src, non_blocking=True)
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.stream):
-                src.record_stream(self.stream)
-                self._work = td.all_gather_into_tensor(out, src.contiguous(), group=self.group, async_op=True)
+                self._work = td.all_gather_into_tensor(out, self.stage, group=self.group, async_op=True)
         else:
-            self._work = td.all_gather_into_tensor(out, src.contiguous(), group=self.group, async_op=True)
+            self._work = td.all_gather_into_tensor(out, self.stage, group=self.group, async_op=True)
         return out
 
     def wait(self) -> None:
