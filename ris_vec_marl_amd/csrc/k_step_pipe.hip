@@ -138,8 +138,9 @@ k_step_fused_pipe(Dims d, RisVecParams P, StepArgs A, int n_groups_total) {
     // no wait on the prefetch - is needed at the loop boundary.
     auto do_group = [&](int g_cur, const StepIn& in, StepIn& in_nx) {
         // The prefetch is unconditional (straight-line code keeps the compiler's vmcnt
-        // bookkeeping exact): a wave on its last group re-reads that group's first D units.
-        const int nxt = (g_cur + nw < n_groups_total) ? g_cur + nw : g_cur;
+        // bookkeeping exact): a wave on its last group "prefetches" group 0 instead, which
+        // every such wave shares, so those requests are served by L2 and cost no HBM traffic.
+        const int nxt = (g_cur + nw < n_groups_total) ? g_cur + nw : 0;
         const int e_mine = g_cur * EPW + lane / VP;
         const bool active = e_mine < d.E;
         // Take the wait for this group's step() inputs HERE (they were requested a whole
