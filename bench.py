@@ -230,7 +230,8 @@ def main() -> None:
     dt = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        on_dev = torch.distributed.get_backend() == "nccl"
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if on_dev else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     # average device time per launch on the launch stream (HIP events bracket the K launches
@@ -268,7 +269,7 @@ def main() -> None:
                    "agent_steps_per_s": E * world * args.steps / dt * V},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"fused": "k_step_fused_pipe<8,64,4>" if (V, M) == (8, 64) else "k_step_fused*",
+                     "kernel": {"fused": "k_step_fused_pipe<8,64,2>" if (V, M) == (8, 64) else "k_step_fused*",
                                 "cached": "k_step", "bcd": "k_bcd_lane + k_step_fused*"}[args.mode],
                      "algorithmic_bytes_per_env_step": per_env, "bytes_per_launch": bytes_per_launch,
                      "avg_launch_ms": kernel_ms},

@@ -210,15 +210,17 @@ k_step_fused_pipe(Dims d, RisVecParams P, StepArgs A, int n_groups_total) {
     }
 }
 
-// waves per CU to launch (each strides over groups); tunable for experiments
+// Waves per CU to launch (each strides over groups) and ring depth.  Measured on MI355X at
+// C3 (E=32768, V=8, M=64), ring depth D x waves/CU -> us per step:
+//   D=1: 26.5 (8)  27.2 (12)  26.6 (16)      D=2: 27.0 (8)  26.7 (12)  26.3 (16)
+//   D=4: 28.0 (4)  27.7 (8)   28.0 (12)      D=8: 29.7 (4)  29.7 (8)   29.6 (12)
+// i.e. a shallow ring with more resident waves wins: deeper rings cost registers (fewer
+// waves) and buy nothing once ~8 waves/CU already keep >= 16 KiB in flight each.
 static int pipe_waves_per_cu() {
     static int v = [] {
         const char* s = std::getenv("RISVEC_PIPE_WAVES_PER_CU");
         const int x = s ? std::atoi(s) : 0;
-        // measured on MI355X (C3, C4 shard, C5 shape): 4 waves/CU (one per SIMD, each with
-        // 4 units = 20 x 1 KiB loads in flight) beats 8 and 12; more concurrent streams cost
-        // more in DRAM locality than they return in latency hiding
-        return (x >= 1 && x <= 32) ? x : 4;
+        return (x >= 1 && x <= 32) ? x : 8;
     }();
     return v;
 }
@@ -243,6 +245,9 @@ static hipError_t launch_pipe(const RisVecState& s, const RisVecParams& p, const
     const int wpb = kBlock / kWave;
     long long want_waves = (long long)num_cus() * pipe_waves_per_cu();
     if (want_waves > n_groups) want_waves = n_groups;
+    // balance: every wave gets the same number of groups (the last one possibly fewer)
+    const long long per_wave = (n_groups + want_waves - 1) / want_waves;
+    want_waves = (n_groups + per_wave - 1) / per_wave;
     const unsigned grid = (unsigned)((want_waves + wpb - 1) / wpb);
     hipLaunchKernelGGL((k_step_fused_pipe<V, M, D>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_groups);
     return hipGetLastError();
@@ -253,11 +258,17 @@ hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, c
     static const bool off = std::getenv("RISVEC_NO_PIPE") != nullptr;    // A/B switch for experiments
     if (off) return hipErrorNotSupported;
     const int V = s.n_veh, M = s.n_ris;
-    if (V == 8 && M == 64) return launch_pipe<8, 64, 4>(s, p, a, st);
-    if (V == 8 && M == 36) return launch_pipe<8, 36, 4>(s, p, a, st);
-    if (V == 8 && M == 40) return launch_pipe<8, 40, 4>(s, p, a, st);
+    if (V == 8 && M == 64) {
+        static const int depth = [] { const char* e = std::getenv("RISVEC_PIPE_DEPTH"); return e ? std::atoi(e) : 2; }();
+        if (depth == 1) return launch_pipe<8, 64, 1>(s, p, a, st);
+        if (depth == 4) return launch_pipe<8, 64, 4>(s, p, a, st);
+        if (depth == 8) return launch_pipe<8, 64, 8>(s, p, a, st);
+        return launch_pipe<8, 64, 2>(s, p, a, st);
+    }
+    if (V == 8 && M == 36) return launch_pipe<8, 36, 2>(s, p, a, st);
+    if (V == 8 && M == 40) return launch_pipe<8, 40, 2>(s, p, a, st);
     if (V == 4 && M == 16) return launch_pipe<4, 16, 4>(s, p, a, st);
-    if (V == 16 && M == 64) return launch_pipe<16, 64, 4>(s, p, a, st);
+    if (V == 16 && M == 64) return launch_pipe<16, 64, 2>(s, p, a, st);
     if (V == 16 && M == 256) return launch_pipe<16, 256, 2>(s, p, a, st);
     return hipErrorNotSupported;
 }

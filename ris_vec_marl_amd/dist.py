@@ -29,11 +29,15 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks (several ranks on a one-GPU box): RISVEC_DIST_BACKEND=gloo keeps RCCL out
+    # of the picture, RISVEC_DEVICE_INDEX pins every rank to one device
+    if "RISVEC_DEVICE_INDEX" in os.environ:
+        local = int(os.environ["RISVEC_DEVICE_INDEX"])
     if world > 1 and not td.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("RISVEC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         td.init_process_group(backend=backend, rank=rank, world_size=world)
