@@ -205,8 +205,12 @@ def main() -> None:
     fused, bcd = args.mode != "cached", args.mode == "bcd"
     full = not args.lean
 
+    # arguments validated and marshalled once; each call is then a single C-ABI launch
+    launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full, power_w=False,
+                           obs=full)
+
     def one_step(i: int) -> None:
-        env.step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full, power_w=False, obs=full)
+        launch()
         if gather is not None and i % args.gather_every == 0:
             gather.start(env.tensors["obs"])
 

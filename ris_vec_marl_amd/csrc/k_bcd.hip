@@ -17,12 +17,16 @@
 // theta, b are the float32 tensors): a float32 sweep would flip near-tied decisions and
 // drift away from the reference's theta.
 //
-// k_bcd_lane (even M): a 256-thread block stages c[] (f64) and theta[] of `epb` envs in
-// LDS - phase 1 streams h_r with 16-byte loads, two lanes per element pair splitting the
-// vehicle rows - then ONE LANE PER ENV walks the chain with no cross-lane traffic, and the
-// block writes theta back coalesced.  LDS capacity (24 B per element per env) bounds the
-// envs in flight per CU, so two blocks per CU alternate streaming and sweeping.
+// k_bcd_lane (even M): a 256-thread block stages c[] (f64) of `epb` envs in LDS - phase 1
+// streams h_r with 16-byte loads, two lanes per element pair splitting the vehicle rows - then
+// ONE LANE PER ENV walks the chain with no cross-lane traffic (theta prefetched from global
+// 16 elements ahead, the new theta parked in the dead c slots), and the block writes theta
+// back coalesced.  The chain is latency-bound, so throughput = envs in flight per CU, which
+// LDS capacity bounds (16 B per element per env): two blocks per CU alternate streaming
+// and sweeping.
 // k_bcd_group (any M): the earlier form, 2^b lanes per env with a butterfly arg-max.
+#include <cstdlib>
+
 #include "risvec_step.hpp"
 
 namespace risvec {
@@ -31,7 +35,7 @@ constexpr int kBcdLdsBudget = 79 * 1024;        // dynamic LDS per block; with t
                                                 // table two blocks fit a CU's 160 KiB
 
 __host__ __device__ constexpr size_t bcd_env_bytes(int M) {
-    return (size_t)(M + 1) * sizeof(double2) + (size_t)(M + 2) * sizeof(float2);
+    return (size_t)(M + 1) * sizeof(double2);
 }
 
 // arg-max_k Re(cand_k q) over the NC = 2^b unit phasors cand_k = exp(j 2 pi k / NC); the
@@ -68,16 +72,16 @@ __device__ __forceinline__ int pick_candidate(double qr, double qi, const double
 
 constexpr int kBcdRows = 8;     // h_r rows a lane keeps in flight per element pair
 
+constexpr int kBcdTheta = 8;    // float4 (= 2 theta values) a sweep lane prefetches per block of 16 steps
+
 template <int NC>
 __global__ void __launch_bounds__(kBlock)
 k_bcd_lane(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ theta,
-           const float* __restrict__ b, int32_t* __restrict__ idx_out) {
+           const float* __restrict__ b, int32_t* __restrict__ idx_out, int dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = d.M, V = d.V, NPAIR = M >> 1;
     const int cstride = M + 1;                   // +16 B: lanes (envs) land on different banks
-    const int tstride = M + 2;
     double2* s_c = reinterpret_cast<double2*>(smem);                      // [epb][cstride]
-    float2* s_th = reinterpret_cast<float2*>(s_c + (size_t)epb * cstride); // [epb][tstride]
     __shared__ double2 s_cand[NC];
     const int tid = threadIdx.x;
     const int e_blk = blockIdx.x * epb;
@@ -94,10 +98,10 @@ k_bcd_lane(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ t
 
     // ---- phase 1: c[i][m] = (sum_v h_r[e,v,m]) b[m].  The (env, element-pair) slots of the
     // block are flattened over the threads, two lanes per slot: lane 2s takes the even vehicle
-    // rows, lane 2s+1 the odd ones (their halves meet through one DPP exchange); each lane
-    // keeps up to kBcdRows 16-byte loads in flight.  The odd lane also stages theta.
+    // rows, lane 2s+1 the odd ones (their halves meet through one DPP exchange, then each
+    // writes one element of the pair); each lane keeps up to kBcdRows 16-byte loads in flight.
     const int vh = tid & 1;
-    const int n_slot = n_env * NPAIR;
+    const int n_slot = (dbg & 2) ? 0 : n_env * NPAIR;
     for (int s0 = 0; s0 < n_slot; s0 += kBlock / 2) {
         const int slot = s0 + (tid >> 1);
         const bool in = slot < n_slot;
@@ -125,76 +129,94 @@ k_bcd_lane(Dims d, int epb, const float* __restrict__ h_r, float* __restrict__ t
         s0r += xchg<1>(s0r); s0i += xchg<1>(s0i);
         s1r += xchg<1>(s1r); s1i += xchg<1>(s1i);
         if (in) {
-            if (vh == 0) {
-                const float4 bb = b4[p];
-                s_c[(size_t)i * cstride + 2 * p] = make_double2(s0r * bb.x - s0i * bb.y, s0r * bb.y + s0i * bb.x);
-                s_c[(size_t)i * cstride + 2 * p + 1] = make_double2(s1r * bb.z - s1i * bb.w, s1r * bb.w + s1i * bb.z);
-            } else {
-                const float4 t = t4[e * NPAIR + p];
-                s_th[(size_t)i * tstride + 2 * p] = make_float2(t.x, t.y);
-                s_th[(size_t)i * tstride + 2 * p + 1] = make_float2(t.z, t.w);
-            }
+            const float4 bb = b4[p];
+            const double sr = vh ? s1r : s0r, si = vh ? s1i : s0i;
+            const double br = vh ? bb.z : bb.x, bi = vh ? bb.w : bb.y;
+            s_c[(size_t)i * cstride + 2 * p + vh] = make_double2(sr * br - si * bi, sr * bi + si * br);
         }
     }
     __syncthreads();
 
-    // ---- phases 2+3: one lane per env
-    if (tid < n_env) {
-        const double2* __restrict__ c = s_c + (size_t)tid * cstride;
-        float2* th = s_th + (size_t)tid * tstride;
+    // ---- phases 2+3: one lane per env.  theta is read straight from global memory, a block
+    // of 2*kBcdTheta elements ahead (the chain below takes microseconds per block); the new
+    // theta is parked in the LDS slot of the element it replaces (c[m] is dead after step m).
+    if (tid < n_env && !(dbg & 1)) {
+        double2* c = s_c + (size_t)tid * cstride;
         const long long e = e_blk + tid;
-        // phase 2: S = sum_m theta_m c_m, four independent chains, fixed order (deterministic)
-        double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};
-        int m = 0;
-        for (; m + 3 < M; m += 4) {
+        const float4* __restrict__ tg = t4 + e * NPAIR;
+        const int n_blk = (NPAIR + kBcdTheta - 1) / kBcdTheta;
+        float4 tcur[kBcdTheta], tnxt[kBcdTheta];
+
+        // phase 2: S = sum_m theta_m c_m, fixed order (deterministic), two chains
+        double Sr = 0.0, Si = 0.0, Tr = 0.0, Ti = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double2 ck = c[m + k];
-                const double tr = th[m + k].x, ti = th[m + k].y;
-                ar[k] += tr * ck.x - ti * ck.y;
-                ai[k] += tr * ck.y + ti * ck.x;
+        for (int j = 0; j < kBcdTheta; ++j) tcur[j] = tg[j < NPAIR ? j : NPAIR - 1];
+        for (int kb = 0; kb < n_blk; ++kb) {
+#pragma unroll
+            for (int j = 0; j < kBcdTheta; ++j) {
+                const int q = (kb + 1) * kBcdTheta + j;
+                tnxt[j] = tg[q < NPAIR ? q : NPAIR - 1];
             }
+#pragma unroll
+            for (int j = 0; j < kBcdTheta; ++j) {
+                const int q = kb * kBcdTheta + j;
+                if (q < NPAIR) {
+                    const double2 c0 = c[2 * q], c1 = c[2 * q + 1];
+                    Sr += (double)tcur[j].x * c0.x - (double)tcur[j].y * c0.y;
+                    Si += (double)tcur[j].x * c0.y + (double)tcur[j].y * c0.x;
+                    Tr += (double)tcur[j].z * c1.x - (double)tcur[j].w * c1.y;
+                    Ti += (double)tcur[j].z * c1.y + (double)tcur[j].w * c1.x;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kBcdTheta; ++j) tcur[j] = tnxt[j];
         }
-        for (; m < M; ++m) {
-            const double2 ck = c[m];
-            const double tr = th[m].x, ti = th[m].y;
-            ar[0] += tr * ck.x - ti * ck.y;
-            ai[0] += tr * ck.y + ti * ck.x;
-        }
-        double Sr = (ar[0] + ar[1]) + (ar[2] + ar[3]), Si = (ai[0] + ai[1]) + (ai[2] + ai[3]);
+        Sr += Tr; Si += Ti;
 
         // phase 3: the chain
-        double2 cm = c[0];
-        float2 tm = th[0];
-        for (m = 0; m < M; ++m) {
-            // next element's operands do not depend on S: fetch them under this step's chain
-            const int mn = m + 1 < M ? m + 1 : m;
-            const double2 cn = c[mn];
-            const float2 tn = th[mn];
-            const double tr = tm.x, ti = tm.y;
+        auto chain_step = [&](int m, double tr, double ti) {
+            const double2 cm = c[m];
             const double rr = Sr - (tr * cm.x - ti * cm.y);
             const double ri = Si - (tr * cm.y + ti * cm.x);
             const double qr = rr * cm.x + ri * cm.y;            // q = conj(rest) * c_m
             const double qi = rr * cm.y - ri * cm.x;
             double nr, ni;
-            int kb = pick_candidate<NC>(qr, qi, s_cand, nr, ni);
+            const int kb = pick_candidate<NC>(qr, qi, s_cand, nr, ni);
             const double nSr = rr + (nr * cm.x - ni * cm.y);
             const double nSi = ri + (nr * cm.y + ni * cm.x);
             const bool none = nSr == 0.0 && nSi == 0.0;         // no candidate scores above 0
             Sr = none ? rr : nSr;
             Si = none ? ri : nSi;
-            th[m] = make_float2(none ? 0.f : (float)nr, none ? 0.f : (float)ni);
+            *reinterpret_cast<float2*>(&c[m]) = make_float2(none ? 0.f : (float)nr, none ? 0.f : (float)ni);
             if (idx_out) idx_out[e * M + m] = none ? -1 : kb;
-            cm = cn; tm = tn;
+        };
+#pragma unroll
+        for (int j = 0; j < kBcdTheta; ++j) tcur[j] = tg[j < NPAIR ? j : NPAIR - 1];
+        for (int kb = 0; kb < n_blk; ++kb) {
+#pragma unroll
+            for (int j = 0; j < kBcdTheta; ++j) {
+                const int q = (kb + 1) * kBcdTheta + j;
+                tnxt[j] = tg[q < NPAIR ? q : NPAIR - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < kBcdTheta; ++j) {
+                const int q = kb * kBcdTheta + j;
+                if (q < NPAIR) {
+                    chain_step(2 * q, (double)tcur[j].x, (double)tcur[j].y);
+                    chain_step(2 * q + 1, (double)tcur[j].z, (double)tcur[j].w);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kBcdTheta; ++j) tcur[j] = tnxt[j];
         }
     }
     __syncthreads();
 
-    // ---- write theta back, coalesced
+    // ---- write theta back, coalesced (it sits in the first 8 bytes of each c slot)
     float2* __restrict__ th_out = reinterpret_cast<float2*>(theta);
     for (int t = tid; t < n_env * M; t += kBlock) {
         const int i = t / M, m = t - i * M;
-        th_out[(long long)(e_blk + i) * M + m] = s_th[(size_t)i * tstride + m];
+        th_out[(long long)(e_blk + i) * M + m] = *reinterpret_cast<const float2*>(&s_c[(size_t)i * cstride + m]);
     }
 }
 
@@ -294,8 +316,9 @@ static hipError_t launch_bcd_nc(const RisVecState& s, int32_t* idx_out, hipStrea
             }
             // spread envs evenly over the blocks actually needed
             const unsigned grid = (unsigned)((s.n_envs + epb - 1) / epb);
+            static const int dbg = [] { const char* e = std::getenv("RISVEC_BCD_DBG"); return e ? std::atoi(e) : 0; }();
             hipLaunchKernelGGL((k_bcd_lane<NC>), dim3(grid), dim3(kBlock), epb * per_env, st, dims_of(s), epb,
-                               s.h_r, s.theta, s.b, idx_out);
+                               s.h_r, s.theta, s.b, idx_out, dbg);
             return hipGetLastError();
         }
     }

@@ -304,6 +304,36 @@ class VecEnviron(ParamAttrs):
         return (t["reward"], t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"],
                 t["over_data"])
 
+    def bind_step(self, action_power, partner, n_groups, arrivals=None, fused: bool = False, bcd: bool = False,
+                  metrics: bool = True, power_w: bool = True, obs: bool = True, policy_action: bool = False):
+        """Validate and marshal a `step()` call ONCE and return a zero-argument callable that
+        launches one step per call on the stream current at bind time, reading the SAME input
+        tensors each time (update them in place between calls).  Cuts the per-step host cost
+        from ~10 us of Python argument handling to one ctypes call, which matters when a
+        batched step is only a few microseconds of GPU time (small E)."""
+        self._ensure_device()
+        E, V = self.n_envs, self.n_veh
+        a = self._arg(action_power, torch.float32, (E, V, 2) if policy_action else (E, 2, V), "action_power")
+        pt = self._arg(partner, torch.int32, (E, V), "partner")
+        ng = self._arg(n_groups, torch.int32, (E,), "n_groups")
+        ar = self._arg(arrivals, torch.int32, (E, V), "arrivals")
+        flags = C.c_uint32((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
+                           | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0))
+        lib = N.load()
+        fn = lib.risvec_step_fused_bcd if bcd else (lib.risvec_step_fused if fused else lib.risvec_step)
+        cs, seed, stream = C.byref(self._cstate), C.c_uint64(self.seed), self._stream()
+        pa, pp, pn, par = _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng), _dev_ptr(ar)
+        keep = (a, pt, ng, ar)           # the closure owns the marshalled tensors
+
+        def launch() -> None:
+            rc = fn(cs, C.byref(self._p()), pa, pp, pn, par, seed, self._steps, flags, stream)
+            if rc:
+                N.check(rc)
+            self._steps += 1
+
+        launch.inputs = keep
+        return launch
+
     # ------------------------------------------------------------------ driver-side helpers
     def observe(self) -> torch.Tensor:
         """marl_train_bcd.py:819-827 for all agents: [E,V,5].  After a step the kernel has

@@ -627,3 +627,24 @@ def test_error_behaviour():
     bad = N.RisVecState()
     assert lib.risvec_gain(C.byref(bad), C.byref(env._p()), None) == N.ERR_ARG
     assert b"ABI" in lib.risvec_last_error()
+
+
+def test_bind_step_equals_step():
+    """The pre-marshalled launcher must be the same computation as step()."""
+    E, V, M = 777, 8, 64
+    rng = np.random.default_rng(12)
+    action, partner, ng, _ = random_step_inputs(E, V, rng)
+    outs = []
+    for bound in (False, True):
+        env = make_vec(E, V, M, seed=3, yaml=True)
+        env.make_new_game(); env.compute_parms(); env.Random_phase()
+        a = torch.from_numpy(action.astype(np.float32)).cuda()
+        run = env.bind_step(a, partner.astype(np.int32), ng.astype(np.int32), None, fused=True) if bound else \
+            (lambda: env.step(a, partner.astype(np.int32), ng.astype(np.int32), None, fused=True))
+        for k in range(3):
+            a.mul_(0.9)                      # inputs are re-read on every launch
+            run()
+        t = env.tensors
+        outs.append([cpu(t[k]).copy() for k in ("reward", "data_buf", "mec_q", "metrics", "obs", "gain")])
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
