@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 3
+#define RISVEC_ABI_VERSION 4
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -57,8 +57,12 @@ enum {
     RISVEC_STEP_POWER_W = 2,        /* write power_w[E,2,V]  (last_power_W, ENV:664-666)   */
     RISVEC_STEP_POLICY_ACTION = 4,  /* `action` is the policy output [E,V,2] in [-1,1]; apply
                                        marl_train_bcd.py:1601-1608 in-kernel             */
-    RISVEC_STEP_OBS = 8             /* write obs[E,V,5] (marl_train_bcd.py:819-827)        */
+    RISVEC_STEP_OBS = 8,            /* write obs[E,V,5] (marl_train_bcd.py:819-827)        */
+    RISVEC_STEP_REUSE_COLSUM = 16   /* risvec_step_fused_bcd: c_col is current, skip its rebuild */
 };
+
+/* risvec_bcd flags */
+enum { RISVEC_BCD_REUSE_COLSUM = 1 };  /* caller guarantees c_col matches h_r and b */
 
 /* Physics / geometry parameters: the attributes of `Environ` that the driver sets
  * (ENV:57-190, overridden by marl_train_bcd.py:548-779).  Passed by value to kernels. */
@@ -138,6 +142,8 @@ typedef struct RisVecState {
     float *obs;             /* [E,V,5] marl_get_state                                 */
     float *metrics;         /* [E,16]  see RISVEC_METRIC_* (slots 14,15 reserved = 0) */
     float *power_w;         /* [E,2,V] last_power_W (may be NULL unless flag set)     */
+    /* BCD cache: c[e,m] = (sum_v h_r[e,v,m]) * b[m] in float64 (pure geometry, like `pl`) */
+    double *c_col;          /* [E,M]   c128; written by risvec_geometry / risvec_colsum */
 } RisVecState;
 
 /* metrics slots (ENV line in comment) */
@@ -194,9 +200,15 @@ int risvec_gain_3gpp(const RisVecState *s, const RisVecParams *p, int32_t model,
                      const float *u_los, const float *z_shadow, const float *small,
                      uint64_t seed, uint32_t counter, risvec_stream_t stream);
 
+/* Column sums for BCD: c_col[e,m] = (sum_v h_r[e,v,m]) * b[m], float64.  One HBM pass over
+ * h_r.  risvec_geometry calls it too, so after compute_parms the cache is current; call it
+ * again after writing h_r directly. */
+int risvec_colsum(const RisVecState *s, risvec_stream_t stream);
+
 /* optimize_phase_shift (ENV:208-220) with the objective of ENV:222-231: one BCD sweep
- * over theta in place.  idx_out [E,M] int32 (optional): chosen candidate, -1 = none. */
-int risvec_bcd(const RisVecState *s, const RisVecParams *p, int32_t *idx_out,
+ * over theta in place.  Rebuilds c_col first unless flags has RISVEC_BCD_REUSE_COLSUM.
+ * idx_out [E,M] int32 (optional): chosen candidate, -1 = none. */
+int risvec_bcd(const RisVecState *s, const RisVecParams *p, int32_t *idx_out, uint32_t flags,
                risvec_stream_t stream);
 
 /* get_next_phase (ENV:233-239): theta = exp(j*angle), angle [E,M] float32. */

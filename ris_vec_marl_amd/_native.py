@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -20,7 +20,8 @@ PARTNER_SECOND = 1 << 16
 OK, ERR_ARG, ERR_SHAPE, ERR_LAUNCH, ERR_UNSUPPORTED = range(5)
 DIR_U, DIR_D, DIR_L, DIR_R = range(4)
 CH_FREE, CH_3GPP_UMI, CH_3GPP_UMA, CH_OTHER = range(4)
-STEP_METRICS, STEP_POWER_W, STEP_POLICY_ACTION, STEP_OBS = 1, 2, 4, 8
+STEP_METRICS, STEP_POWER_W, STEP_POLICY_ACTION, STEP_OBS, STEP_REUSE_COLSUM = 1, 2, 4, 8, 16
+BCD_REUSE_COLSUM = 1
 
 METRIC_NAMES = (
     "global_reward", "last_off_kbit_sum", "last_local_kbit_sum", "last_mec_queue_cycles",
@@ -63,7 +64,7 @@ class RisVecState(C.Structure):
         ("theta", _FP), ("b", _FP), ("h_d", _FP), ("gain", _FP),
         ("data_buf", _FP), ("mec_q", _FP),
         ("rate", _FP), ("data_t", _FP), ("data_p", _FP), ("reward", _FP), ("over_power", _FP),
-        ("obs", _FP), ("metrics", _FP), ("power_w", _FP),
+        ("obs", _FP), ("metrics", _FP), ("power_w", _FP), ("c_col", _FP),
     ]
 
 
@@ -81,7 +82,8 @@ _PROTOS = {
     "risvec_gain": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP]),
     "risvec_gain_3gpp": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), C.c_int32,
                                    _FP, _FP, _FP, C.c_uint64, C.c_uint32, _FP]),
-    "risvec_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP]),
+    "risvec_colsum": (C.c_int, [C.POINTER(RisVecState), _FP]),
+    "risvec_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, C.c_uint32, _FP]),
     "risvec_set_phase": (C.c_int, [C.POINTER(RisVecState), _FP, _FP]),
     "risvec_random_phase": (C.c_int, [C.POINTER(RisVecState), _FP, C.c_uint64, C.c_uint32, _FP]),
     "risvec_step": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP, _FP, _FP,

@@ -72,7 +72,8 @@ int check_step(const char* fn, const RisVecState* s, const float* action, const 
     REQ_PTR(s->metrics, "state.metrics");
     if (flags & RISVEC_STEP_OBS) REQ_PTR(s->obs, "state.obs");
     if (flags & RISVEC_STEP_POWER_W) REQ_PTR(s->power_w, "state.power_w");
-    if (flags & ~(uint32_t)(RISVEC_STEP_METRICS | RISVEC_STEP_POWER_W | RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS))
+    if (flags & ~(uint32_t)(RISVEC_STEP_METRICS | RISVEC_STEP_POWER_W | RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS |
+                            RISVEC_STEP_REUSE_COLSUM))
         return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
     if (fused) {
         REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->b, "state.b");
@@ -158,7 +159,13 @@ int risvec_geometry(const RisVecState* s, const RisVecParams* p, risvec_stream_t
     if (int rc = check_common(fn, s, p)) return rc;
     REQ_PTR(s->pos, "state.pos"); REQ_PTR(s->dist_r, "state.dist_r"); REQ_PTR(s->ang_r, "state.ang_r");
     REQ_PTR(s->pl, "state.pl"); REQ_PTR(s->h_r, "state.h_r");
-    return finish(fn, risvec::launch_geometry(*s, *p, (hipStream_t)stream));
+    OPT_PTR(s->c_col, "state.c_col");
+    if (int rc = finish(fn, risvec::launch_geometry(*s, *p, (hipStream_t)stream))) return rc;
+    if (s->c_col) {                      // keep the BCD column-sum cache in step with h_r
+        REQ_PTR(s->b, "state.b");
+        return finish(fn, risvec::launch_colsum(*s, (hipStream_t)stream));
+    }
+    return RISVEC_OK;
 }
 
 int risvec_gain(const RisVecState* s, const RisVecParams* p, risvec_stream_t stream) {
@@ -187,13 +194,23 @@ int risvec_gain_3gpp(const RisVecState* s, const RisVecParams* p, int32_t model,
                                                (hipStream_t)stream));
 }
 
-int risvec_bcd(const RisVecState* s, const RisVecParams* p, int32_t* idx_out, risvec_stream_t stream) {
+int risvec_colsum(const RisVecState* s, risvec_stream_t stream) {
+    const char* fn = "risvec_colsum";
+    if (int rc = check_common(fn, s, nullptr)) return rc;
+    REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->b, "state.b"); REQ_PTR(s->c_col, "state.c_col");
+    return finish(fn, risvec::launch_colsum(*s, (hipStream_t)stream));
+}
+
+int risvec_bcd(const RisVecState* s, const RisVecParams* p, int32_t* idx_out, uint32_t flags,
+               risvec_stream_t stream) {
     const char* fn = "risvec_bcd";
     if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     if (int rc = check_common(fn, s, p)) return rc;
     REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->b, "state.b");
+    REQ_PTR(s->c_col, "state.c_col");
     OPT_PTR(idx_out, "idx_out");
-    return finish(fn, risvec::launch_bcd(*s, *p, idx_out, (hipStream_t)stream));
+    if (flags & ~(uint32_t)RISVEC_BCD_REUSE_COLSUM) return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
+    return finish(fn, risvec::launch_bcd(*s, *p, idx_out, (flags & RISVEC_BCD_REUSE_COLSUM) != 0, (hipStream_t)stream));
 }
 
 int risvec_set_phase(const RisVecState* s, const float* angle, risvec_stream_t stream) {
@@ -250,6 +267,7 @@ int risvec_step_fused_bcd(const RisVecState* s, const RisVecParams* p, const flo
     if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     if (int rc = check_common(fn, s, p)) return rc;
     if (int rc = check_step(fn, s, action, partner, n_groups, arrivals, flags, true)) return rc;
+    REQ_PTR(s->c_col, "state.c_col");
     return finish(fn, risvec::launch_step_fused_bcd(*s, *p, action, partner, n_groups, arrivals, seed,
                                                     counter, flags, (hipStream_t)stream));
 }

@@ -90,6 +90,7 @@ class VecEnviron(ParamAttrs):
         self._steps = 0          # step counter    (RNG counter for arrivals)
         self._chan = 0           # 3GPP-gain / random-phase counter
         self._t: Dict[str, torch.Tensor] = {}
+        self._colsum_valid = False     # c_col matches h_r (set by compute_parms / rebuild_colsum)
         self._cstate: Optional[N.RisVecState] = None
         self._cparams: Optional[N.RisVecParams] = None
         self._cparams_version = -1
@@ -128,13 +129,14 @@ class VecEnviron(ParamAttrs):
         t["obs"] = z(E, V, 5)
         t["metrics"] = z(E, N.METRICS)
         t["power_w"] = z(E, 2, V)
+        t["c_col"] = z(E, M, 2, dt=torch.float64)      # BCD column sums (sum_v h_r) * b, f64
         s = N.RisVecState()
         s.abi_version = N.ABI_VERSION
         s.struct_bytes = C.sizeof(N.RisVecState)
         s.n_envs, s.n_veh, s.n_ris, s.control_bit = E, V, M, self.control_bit
         s.env_offset = self.env_offset
         for k in ("pos", "dir", "vel", "dist_r", "ang_r", "pl", "h_r", "theta", "b", "gain", "data_buf",
-                  "mec_q", "rate", "data_t", "data_p", "reward", "over_power", "obs", "metrics", "power_w"):
+                  "mec_q", "rate", "data_t", "data_p", "reward", "over_power", "obs", "metrics", "power_w", "c_col"):
             setattr(s, k, t[k].data_ptr())
         s.h_d = None
         self._cstate = s
@@ -219,12 +221,29 @@ class VecEnviron(ParamAttrs):
         """Environment.py:241-253: pos -> distances_R_i, angles_R_i, phases_R_i (+ path-loss factor)."""
         self._ensure_device()
         N.check(N.load().risvec_geometry(C.byref(self._cstate), C.byref(self._p()), self._stream()))
+        self._colsum_valid = True
 
-    def optimize_phase_shift(self, return_idx: bool = False):
-        """Environment.py:208-220 (one BCD sweep, objective of :222-231)."""
+    def rebuild_colsum(self) -> None:
+        """Recompute the BCD cache c_col[e,m] = (sum_v h_r[e,v,m]) b[m] (float64).  compute_parms()
+        does it already; call this after writing `tensors["h_r"]` directly."""
+        self._ensure_device()
+        N.check(N.load().risvec_colsum(C.byref(self._cstate), self._stream()))
+        self._colsum_valid = True
+
+    def invalidate_colsum(self) -> None:
+        """Tell the env that h_r was modified behind its back: the next BCD rebuilds c_col."""
+        self._colsum_valid = False
+
+    def optimize_phase_shift(self, return_idx: bool = False, reuse_colsum: Optional[bool] = None):
+        """Environment.py:208-220 (one BCD sweep, objective of :222-231).  The column sums the
+        sweep needs are pure geometry; they are reused when known current (after
+        compute_parms()/rebuild_colsum()), otherwise rebuilt first.  reuse_colsum overrides."""
         self._ensure_device()
         idx = torch.zeros(self.n_envs, self.M, dtype=torch.int32, device=self.device) if return_idx else None
-        N.check(N.load().risvec_bcd(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(idx), self._stream()))
+        reuse = self._colsum_valid if reuse_colsum is None else bool(reuse_colsum)
+        N.check(N.load().risvec_bcd(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(idx),
+                                    N.BCD_REUSE_COLSUM if reuse else 0, self._stream()))
+        self._colsum_valid = True
         return idx
 
     def update_channel_gains(self, u_los=None, z_shadow=None, small=None) -> None:
@@ -294,7 +313,8 @@ class VecEnviron(ParamAttrs):
         ng = self._arg(n_groups, torch.int32, (E,), "n_groups")
         ar = self._arg(arrivals, torch.int32, (E, V), "arrivals")
         flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
-                 | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0))
+                 | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0)
+                 | (N.STEP_REUSE_COLSUM if (bcd and self._colsum_valid) else 0))
         lib = N.load()
         fn = lib.risvec_step_fused_bcd if bcd else (lib.risvec_step_fused if fused else lib.risvec_step)
         N.check(fn(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng),
@@ -318,7 +338,8 @@ class VecEnviron(ParamAttrs):
         ng = self._arg(n_groups, torch.int32, (E,), "n_groups")
         ar = self._arg(arrivals, torch.int32, (E, V), "arrivals")
         flags = C.c_uint32((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
-                           | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0))
+                           | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0)
+                           | (N.STEP_REUSE_COLSUM if (bcd and self._colsum_valid) else 0))
         lib = N.load()
         fn = lib.risvec_step_fused_bcd if bcd else (lib.risvec_step_fused if fused else lib.risvec_step)
         cs, seed, stream = C.byref(self._cstate), C.c_uint64(self.seed), self._stream()
@@ -381,6 +402,7 @@ class VecEnviron(ParamAttrs):
         t = self.tensors
         for k in self._STATE_KEYS:
             t[k].copy_(sd[k])
+        self._colsum_valid = False
         c = sd["counters"]
         self._epoch, self._moves, self._steps, self._chan = c["epoch"], c["moves"], c["steps"], c["chan"]
 

@@ -648,3 +648,35 @@ def test_bind_step_equals_step():
         outs.append([cpu(t[k]).copy() for k in ("reward", "data_buf", "mec_q", "metrics", "obs", "gain")])
     for x, y in zip(*outs):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("V,M", [(8, 64), (5, 21), (16, 256)])
+def test_colsum_cache(V, M):
+    """c_col = (sum_v h_r) * b in float64: built by compute_parms / rebuild_colsum, reused by BCD."""
+    E = 130
+    rng = np.random.default_rng(V + M)
+    env = make_vec(E, V, M)
+    t = env.tensors
+    t["pos"].copy_(torch.from_numpy(np.stack([rng.uniform(0, 400, (E, V)), rng.uniform(0, 400, (E, V))], -1)))
+    env.compute_parms()
+
+    def want():
+        return c128(t["h_r"]).sum(axis=1) * c128(t["b"])[None, :]
+    got = cpu(t["c_col"]); got = got[..., 0] + 1j * got[..., 1]
+    np.testing.assert_allclose(got, want(), rtol=1e-14, atol=1e-14)
+    # direct write to h_r: the cache is stale until rebuilt
+    put_complex(t["h_r"], c128(t["h_r"]) * np.exp(1j * rng.uniform(0, 6.28, (E, V, M))))
+    env.rebuild_colsum()
+    got = cpu(t["c_col"]); got = got[..., 0] + 1j * got[..., 1]
+    np.testing.assert_allclose(got, want(), rtol=1e-14, atol=1e-14)
+    # a sweep that reuses the cache == a sweep that rebuilds it, bit for bit
+    env.Random_phase(); th0 = t["theta"].clone()
+    i1 = cpu(env.optimize_phase_shift(return_idx=True, reuse_colsum=True)).copy(); th1 = cpu(t["theta"]).copy()
+    t["theta"].copy_(th0)
+    i2 = cpu(env.optimize_phase_shift(return_idx=True, reuse_colsum=False))
+    assert np.array_equal(i1, i2) and np.array_equal(th1, cpu(t["theta"]))
+    # and matches the oracle on the same float32 inputs
+    o_th, o_idx = orc.bcd_sweep(c128(th0), c128(t["h_r"]), c128(t["b"]), np.ones((E, V)), 3)
+    gap = orc.bcd_margin(c128(th0), c128(t["h_r"]), c128(t["b"]), 3)
+    safe = np.minimum.accumulate(gap, axis=1) > 1e-9
+    assert safe.mean() > 0.98 and np.array_equal(i1[safe], o_idx[safe])
