@@ -144,7 +144,26 @@ typedef struct RisVecState {
     float *power_w;         /* [E,2,V] last_power_W (may be NULL unless flag set)     */
     /* BCD cache: c[e,m] = (sum_v h_r[e,v,m]) * b[m] in float64 (pure geometry, like `pl`) */
     double *c_col;          /* [E,M]   c128; written by risvec_geometry / risvec_colsum */
+    /* SARL variant only (Simulation-SARL/Environment.py:337-340); the MARL step never writes it */
+    float *over_data;       /* [E,V]   (may be NULL for MARL-only use)                 */
 } RisVecState;
+
+/* Parameters of the single-agent (SARL) environment variant,
+ * Simulation-SARL/Environment.py:66-83 (SENV). */
+typedef struct RisVecSarlParams {
+    uint32_t abi_version;
+    uint32_t struct_bytes;
+    float time_fast;        /* SENV:67 */
+    float bandwidth_mhz;    /* SENV:69 */
+    float k_cpu;            /* SENV:70 */
+    float cycles_l;         /* SENV:71  L */
+    float t_factor1;        /* SENV:80 */
+    float t_factor2;        /* SENV:81 */
+    float penalty1;         /* SENV:82 */
+    float penalty2;         /* SENV:83 */
+    float arrival_rate;     /* SENV:78 */
+    float poisson_cdf[RISVEC_POISSON_TABLE];
+} RisVecSarlParams;
 
 /* metrics slots (ENV line in comment) */
 enum {
@@ -238,6 +257,17 @@ int risvec_data_rate(const RisVecState *s, const RisVecParams *p, const float *p
 int risvec_step_fused(const RisVecState *s, const RisVecParams *p, const float *action,
                       const int32_t *partner, const int32_t *n_groups, const int32_t *arrivals,
                       uint64_t seed, uint32_t counter, uint32_t flags, risvec_stream_t stream);
+
+/* SARL variant: Simulation-SARL/Environment.py step(action_power, action_phase)
+ * SENV:321-359 for every env: get_next_phase (theta = exp(j*action_phase), action_phase [E,M]
+ * float32 radians; NULL keeps the current theta), the RIS cascaded gain, natural-log rate against
+ * sigma^2 = 1e-14, cube-root local-CPU model, buffer-length reward with its two penalties,
+ * Poisson arrivals.  action_power [E,2,V] is used as given (no projection).  Outputs: data_buf,
+ * data_t, data_p, over_power, over_data, rate, reward [E,V] and the mean reward in
+ * metrics[e,0]; with RISVEC_STEP_OBS also obs[E,V,5] = the non-theta tail of ddpg_train.py:47-73. */
+int risvec_sarl_step(const RisVecState *s, const RisVecSarlParams *p, const float *action_power,
+                     const float *action_phase, const int32_t *arrivals, uint64_t seed,
+                     uint32_t counter, uint32_t flags, risvec_stream_t stream);
 
 /* BCD sweep + gains + step in one launch (BASELINE config 5: h_r read once into LDS). */
 int risvec_step_fused_bcd(const RisVecState *s, const RisVecParams *p, const float *action,

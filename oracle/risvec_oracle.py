@@ -721,3 +721,67 @@ def bcd_margin(theta, h_r, b, control_bit):
         theta[:, m] = np.where(xs[:, -1] > 0, cand[k], 0)
         S = rest + theta[:, m] * c[:, m]
     return gap
+
+
+# --------------------------------------------------------------------------
+# f1: the single-agent (SARL) environment variant -- Simulation-SARL/Environment.py (SENV)
+# --------------------------------------------------------------------------
+@dataclasses.dataclass
+class SarlParams:
+    """SENV:66-83 class defaults."""
+    time_fast: float = 0.001       # SENV:67
+    bandwidth: float = 1.0         # SENV:69
+    k: float = 1e-28               # SENV:70
+    L: float = 500.0               # SENV:71
+    rate: float = 3.0              # SENV:78
+    t_factor1: float = 1.0         # SENV:80
+    t_factor2: float = 0.6         # SENV:81
+    penalty1: float = 2.0          # SENV:82
+    penalty2: float = 2.0          # SENV:83
+
+
+def sarl_step(data_buf: np.ndarray, gain: np.ndarray, action_power: np.ndarray, arrivals: np.ndarray,
+              p: SarlParams) -> Dict[str, np.ndarray]:
+    """SENV:321-359 for E envs, given the cascaded gain |ro img / (sqrt(d^a1) sqrt(dBR^a2))|^2 of
+    SENV:149-157 (identical to the MARL 'free' gain; the phases come from the agent through
+    get_next_phase, SENV:133-139).  action_power [E,2,V]: row 0 offload power, row 1 local
+    power, used as given (no projection).  Returns the 6-tuple members + rate."""
+    a = np.asarray(action_power, dtype=np.float64)
+    B = np.asarray(data_buf, dtype=np.float64)
+    p0, p1 = a[:, 0, :], a[:, 1, :]
+    rate = np.log(1 + p0 * gain / SIGMA ** 2)                              # SENV:159 (natural log)
+    data_t = rate * p.time_fast * p.bandwidth * 1000                      # SENV:329
+    data_p = np.power(p1 / p.k, 1.0 / 3.0) * p.time_fast / p.L / 1000     # SENV:330
+    Bn = B - (data_t + data_p)                                            # SENV:333
+    neg = Bn < 0
+    need = np.fmax(0, Bn + data_p)                                        # SENV:336
+    proc_rev = np.power(need * 1000 * p.L / p.time_fast, 3.0) * p.k       # SENV:318-319
+    over_power = np.where(neg, p1 - proc_rev, 0.0)                        # SENV:336
+    over_data = np.where(neg, -Bn, 0.0)                                   # SENV:337, 340
+    Bn = np.where(neg, 0.0, Bn)                                           # SENV:338
+    base = -(p.t_factor1 * (p0 + p1)) - p.t_factor2 * Bn                  # SENV:344-352
+    reward = np.where(Bn > 0, base - p.penalty1, np.where(over_data > 2, base - p.penalty2, base))
+    arr = np.asarray(arrivals, dtype=np.float64)
+    B_out = Bn + arr * p.time_fast * 1000                                 # SENV:354-356
+    return dict(reward_mean=reward.mean(axis=1), reward=reward, data_buf=B_out, data_t=data_t, data_p=data_p,
+                over_power=over_power, over_data=over_data, vehicle_rate=rate,
+                margin=dict(buf=B - (data_t + data_p), over=over_data - 2.0))
+
+
+def sarl_obs(theta_real: np.ndarray, data_buf, data_t, data_p, over_data, rate) -> np.ndarray:
+    """ddpg_train.py:47-73: per agent [theta slice (M//V), DataBuf/10, data_t/10, data_p/10,
+    over_data/10, rate/20] -> [E, V, M//V + 5]."""
+    E, V = data_buf.shape
+    tn = theta_real.shape[1] // V
+    th = theta_real[:, :tn * V].reshape(E, V, tn)
+    tail = np.stack([data_buf / 10, data_t / 10, data_p / 10, over_data / 10, rate / 20], axis=2)
+    return np.concatenate([th, tail], axis=2)
+
+
+def sarl_action_map(action: np.ndarray, V: int, M: int) -> Tuple[np.ndarray, np.ndarray]:
+    """ddpg_train.py:149-158: agent output [E, 2V+M] in [-1,1] -> (action_power [E,2,V],
+    action_phase [E,M] in [0, 2 pi))."""
+    a = np.clip(action, -0.999, 0.999)
+    power = np.stack([(a[:, :V] + 1) / 2, (a[:, V:2 * V] + 1) / 2], axis=1)
+    phase = ((a[:, 2 * V:2 * V + M] + 1) / 2) * math.pi * 2
+    return power, phase

@@ -9,7 +9,9 @@ importing the package does not need a GPU, computing does.
 from .params import EnvParams, apply_yaml_config, load_yaml, reference_lanes, poisson_cdf_table
 from .vec_env import VecEnviron
 from .compat import Environ, Vehicle, encode_noma_groups
+from .sarl import SarlEnviron, SarlParams, sarl_action_map, sarl_observe
 from . import dist
 
 __all__ = ["EnvParams", "apply_yaml_config", "load_yaml", "reference_lanes", "poisson_cdf_table",
-           "VecEnviron", "Environ", "Vehicle", "encode_noma_groups", "dist"]
+           "VecEnviron", "Environ", "Vehicle", "encode_noma_groups", "SarlEnviron", "SarlParams", "sarl_action_map",
+           "sarl_observe", "dist"]

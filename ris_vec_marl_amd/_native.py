@@ -64,7 +64,16 @@ class RisVecState(C.Structure):
         ("theta", _FP), ("b", _FP), ("h_d", _FP), ("gain", _FP),
         ("data_buf", _FP), ("mec_q", _FP),
         ("rate", _FP), ("data_t", _FP), ("data_p", _FP), ("reward", _FP), ("over_power", _FP),
-        ("obs", _FP), ("metrics", _FP), ("power_w", _FP), ("c_col", _FP),
+        ("obs", _FP), ("metrics", _FP), ("power_w", _FP), ("c_col", _FP), ("over_data", _FP),
+    ]
+
+
+class RisVecSarlParams(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("struct_bytes", C.c_uint32),
+        ("time_fast", C.c_float), ("bandwidth_mhz", C.c_float), ("k_cpu", C.c_float), ("cycles_l", C.c_float),
+        ("t_factor1", C.c_float), ("t_factor2", C.c_float), ("penalty1", C.c_float), ("penalty2", C.c_float),
+        ("arrival_rate", C.c_float), ("poisson_cdf", C.c_float * POISSON_TABLE),
     ]
 
 
@@ -91,6 +100,8 @@ _PROTOS = {
     "risvec_data_rate": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP, _FP, _FP, _FP]),
     "risvec_step_fused": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP, _FP,
                                     _FP, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
+    "risvec_sarl_step": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecSarlParams), _FP, _FP, _FP,
+                                   C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
     "risvec_step_fused_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP,
                                         _FP, _FP, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
 }

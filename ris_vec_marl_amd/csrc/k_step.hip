@@ -21,43 +21,6 @@
 
 namespace risvec {
 
-// ---------------------------------------------------------------------------
-// cascade: sum_m theta[e,m] b[m] h_r[e,v,m] over a G-lane group.
-// VEC = complex elements per load (2 -> float4, needs M even; 1 -> float2).
-// ---------------------------------------------------------------------------
-template <int G, int VEC>
-__device__ __forceinline__ float2 cascade_row(const float* __restrict__ hrow,
-                                              const float* __restrict__ trow,
-                                              const float* __restrict__ b, int M, int gl, bool valid) {
-    float2 acc = make_float2(0.f, 0.f);
-    if (VEC == 2) {
-        const int npair = M >> 1;
-        for (int p = gl; p < npair; p += G) {
-            if (valid) {
-                const float4 h = *reinterpret_cast<const float4*>(hrow + 4 * p);
-                const float4 t = *reinterpret_cast<const float4*>(trow + 4 * p);
-                const float4 bb = *reinterpret_cast<const float4*>(b + 4 * p);
-                const float2 w0 = cmul(make_float2(t.x, t.y), make_float2(bb.x, bb.y));
-                const float2 w1 = cmul(make_float2(t.z, t.w), make_float2(bb.z, bb.w));
-                acc = cfma(make_float2(h.x, h.y), w0, acc);
-                acc = cfma(make_float2(h.z, h.w), w1, acc);
-            }
-        }
-    } else {
-        for (int m = gl; m < M; m += G) {
-            if (valid) {
-                const float2 h = *reinterpret_cast<const float2*>(hrow + 2 * m);
-                const float2 t = *reinterpret_cast<const float2*>(trow + 2 * m);
-                const float2 bb = *reinterpret_cast<const float2*>(b + 2 * m);
-                acc = cfma(h, cmul(t, bb), acc);
-            }
-        }
-    }
-    acc.x = gsum<G>(acc.x);
-    acc.y = gsum<G>(acc.y);
-    return acc;
-}
-
 // K3: standalone gain kernel, one G-lane group per (env, vehicle)
 template <int G, int VEC>
 __global__ void __launch_bounds__(kBlock)
@@ -146,17 +109,6 @@ k_step_fused(Dims d, RisVecParams P, StepArgs A) {
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-
-// lanes per (env, vehicle) row: enough to cover M/VEC elements in one pass when
-// possible, but never more vehicles per pass than an env has (keeps lanes busy).
-static int pick_group(int M, int vec, int VP) {
-    int g = pow2_ceil((M + vec - 1) / vec);
-    if (g > kWave) g = kWave;
-    const int gmin = kWave / VP;             // >= this => vehicles per pass <= VP
-    if (g < gmin) g = gmin;
-    if (g < 8) g = 8;
-    return g;
-}
 
 template <int G>
 static hipError_t launch_gain_g(const RisVecState& s, hipStream_t st) {

@@ -260,6 +260,27 @@ int risvec_step_fused(const RisVecState* s, const RisVecParams* p, const float* 
                                           true, (hipStream_t)stream));
 }
 
+int risvec_sarl_step(const RisVecState* s, const RisVecSarlParams* p, const float* action_power,
+                     const float* action_phase, const int32_t* arrivals, uint64_t seed, uint32_t counter,
+                     uint32_t flags, risvec_stream_t stream) {
+    const char* fn = "risvec_sarl_step";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (p->abi_version != RISVEC_ABI_VERSION || p->struct_bytes != sizeof(RisVecSarlParams))
+        return fail(RISVEC_ERR_ARG, "%s: RisVecSarlParams ABI mismatch (version %u/%u, bytes %u/%zu)", fn,
+                    p->abi_version, (unsigned)RISVEC_ABI_VERSION, p->struct_bytes, sizeof(RisVecSarlParams));
+    if (int rc = check_common(fn, s, nullptr)) return rc;
+    REQ_PTR(action_power, "action_power"); OPT_PTR(action_phase, "action_phase"); OPT_PTR(arrivals, "arrivals");
+    REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->b, "state.b"); REQ_PTR(s->pl, "state.pl");
+    REQ_PTR(s->gain, "state.gain"); REQ_PTR(s->data_buf, "state.data_buf"); REQ_PTR(s->rate, "state.rate");
+    REQ_PTR(s->data_t, "state.data_t"); REQ_PTR(s->data_p, "state.data_p"); REQ_PTR(s->reward, "state.reward");
+    REQ_PTR(s->over_power, "state.over_power"); REQ_PTR(s->over_data, "state.over_data");
+    REQ_PTR(s->metrics, "state.metrics");
+    if (flags & RISVEC_STEP_OBS) REQ_PTR(s->obs, "state.obs");
+    if (flags & ~(uint32_t)RISVEC_STEP_OBS) return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
+    return finish(fn, risvec::launch_sarl_step(*s, *p, action_power, action_phase, arrivals, seed, counter, flags,
+                                               (hipStream_t)stream));
+}
+
 int risvec_step_fused_bcd(const RisVecState* s, const RisVecParams* p, const float* action,
                           const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals,
                           uint64_t seed, uint32_t counter, uint32_t flags, risvec_stream_t stream) {

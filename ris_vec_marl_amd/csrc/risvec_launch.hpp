@@ -38,6 +38,10 @@ hipError_t launch_step_fused_bcd(const RisVecState& s, const RisVecParams& p, co
                                  const int32_t* arrivals, uint64_t seed, uint32_t counter,
                                  uint32_t flags, hipStream_t st);
 
+hipError_t launch_sarl_step(const RisVecState& s, const RisVecSarlParams& p, const float* action_power,
+                            const float* action_phase, const int32_t* arrivals, uint64_t seed,
+                            uint32_t counter, uint32_t flags, hipStream_t st);
+
 inline Dims dims_of(const RisVecState& s) {
     return Dims{s.n_envs, s.n_veh, s.n_ris, s.control_bit, (long long)s.env_offset};
 }

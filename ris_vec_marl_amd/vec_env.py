@@ -136,7 +136,8 @@ class VecEnviron(ParamAttrs):
         s.n_envs, s.n_veh, s.n_ris, s.control_bit = E, V, M, self.control_bit
         s.env_offset = self.env_offset
         for k in ("pos", "dir", "vel", "dist_r", "ang_r", "pl", "h_r", "theta", "b", "gain", "data_buf",
-                  "mec_q", "rate", "data_t", "data_p", "reward", "over_power", "obs", "metrics", "power_w", "c_col"):
+                  "mec_q", "rate", "data_t", "data_p", "reward", "over_power", "obs", "metrics", "power_w", "c_col",
+                  "over_data"):
             setattr(s, k, t[k].data_ptr())
         s.h_d = None
         self._cstate = s
@@ -323,6 +324,26 @@ class VecEnviron(ParamAttrs):
         t = self._t
         return (t["reward"], t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"],
                 t["over_data"])
+
+    def sarl_step(self, action_power, action_phase=None, arrivals=None, sarl_params=None, obs: bool = True
+                  ) -> Tuple[torch.Tensor, ...]:
+        """The single-agent variant's step (Simulation-SARL/Environment.py:321-359) for every env:
+        action_power [E,2,V] float32 used as given, action_phase [E,M] radians (None keeps the
+        current theta), arrivals [E,V] int32 injected Poisson draws (None: Philox).  Returns the
+        reference's 6-tuple, batched: (Reward [E], DataBuf, data_t, data_p, over_power, over_data)."""
+        from .sarl import SarlParams
+        self._ensure_device()
+        E, V, M = self.n_envs, self.n_veh, self.M
+        a = self._arg(action_power, torch.float32, (E, 2, V), "action_power")
+        ph = self._arg(action_phase, torch.float32, (E, M), "action_phase")
+        ar = self._arg(arrivals, torch.int32, (E, V), "arrivals")
+        sp = (sarl_params or SarlParams()).to_c()
+        N.check(N.load().risvec_sarl_step(C.byref(self._cstate), C.byref(sp), _dev_ptr(a), _dev_ptr(ph),
+                                          _dev_ptr(ar), self.seed, self._steps, N.STEP_OBS if obs else 0,
+                                          self._stream()))
+        self._steps += 1
+        t = self._t
+        return (t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"], t["over_data"])
 
     def bind_step(self, action_power, partner, n_groups, arrivals=None, fused: bool = False, bcd: bool = False,
                   metrics: bool = True, power_w: bool = True, obs: bool = True, policy_action: bool = False):

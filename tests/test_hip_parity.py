@@ -680,3 +680,83 @@ def test_colsum_cache(V, M):
     gap = orc.bcd_margin(c128(th0), c128(t["h_r"]), c128(t["b"]), 3)
     safe = np.minimum.accumulate(gap, axis=1) > 1e-9
     assert safe.mean() > 0.98 and np.array_equal(i1[safe], o_idx[safe])
+
+
+# ---------------------------------------------------------------------------- f1: SARL variant
+@pytest.mark.parametrize("name", ["sarl_step_8_40", "sarl_step_4_16"])
+def test_sarl_step_golden(name):
+    """Simulation-SARL/Environment.py step(action_power, action_phase) (SENV:321-359), every
+    golden sample as one env of a batch; geometry and theta are produced on the device."""
+    g = load(name + ".npz")
+    E, V = g["data_buf0"].shape
+    M = g["theta"].shape[1]
+    env = make_vec(E, V, M)
+    t = env.tensors
+    t["pos"].copy_(torch.from_numpy(g["pos"]))
+    env.compute_parms()
+    t["data_buf"].copy_(torch.from_numpy(g["data_buf0"].astype(np.float32)))
+    out = env.sarl_step(g["action_power"].astype(np.float32), g["action_phase"].astype(np.float32),
+                        g["arrivals"].astype(np.int32))
+    np.testing.assert_allclose(c128(t["theta"]), g["theta"], rtol=0, atol=3e-7)     # exp(j*angle), angle < 2 pi
+    gain_ref = orc.gain_free(g["theta"], g["h_r"], g["b"], g["dist"])
+    img = np.einsum("em,evm,m->ev", g["theta"], g["h_r"], g["b"])
+    # the float32 angle itself carries 2e-7 rad: |delta img| <= ~(4 eps + 2.4e-7) * M
+    atol = orc.pathloss_factor(g["dist"]) * 2 * np.abs(img) * (5e-7 * M)
+    assert (np.abs(cpu(t["gain"]) - gain_ref) <= RT * gain_ref + atol).all()
+    # step parity is judged with the device's own gains as input (gain parity asserted above)
+    o = orc.sarl_step(g["data_buf0"], cpu(t["gain"]).astype(np.float64), g["action_power"], g["arrivals"],
+                      orc.SarlParams())
+    near = (np.abs(o["margin"]["buf"]) < 2e-5) | (np.abs(o["margin"]["over"]) < 2e-5)
+    ok = ~near
+    assert ok.mean() > 0.98
+    np.testing.assert_allclose(cpu(t["rate"]), o["vehicle_rate"], rtol=RT, atol=1e-7)
+    np.testing.assert_allclose(cpu(out[2]), o["data_t"], rtol=RT, atol=1e-7)
+    np.testing.assert_allclose(cpu(out[3]), o["data_p"], rtol=RT, atol=1e-7)
+    kb = np.maximum(g["data_buf0"], 1.0)
+    assert (np.abs(cpu(out[1]) - o["data_buf"])[ok] <= (RT * o["data_buf"] + 4e-7 * kb)[ok]).all()
+    assert (np.abs(cpu(out[5]) - o["over_data"])[ok] <= (RT * o["over_data"] + 4e-7 * kb)[ok]).all()
+    # over_power = p1 - k (need*1000*L/tf)^3: both terms O(p1) or larger, cubic in `need`
+    p1 = g["action_power"][:, 1, :]
+    proc = np.where(o["over_data"] > 0, p1 - o["over_power"], 0.0)
+    assert (np.abs(cpu(out[4]) - o["over_power"])[ok] <= (RT * np.maximum(p1, proc) + 3e-6 * proc + 1e-7)[ok]).all()
+    env_ok = ok.all(axis=1)
+    np.testing.assert_allclose(cpu(out[0])[env_ok], o["reward_mean"][env_ok], rtol=2e-5, atol=2e-6)
+    # and the reference's own numbers
+    np.testing.assert_allclose(cpu(out[0])[env_ok], g["reward_mean"][env_ok], rtol=1e-4, atol=1e-5)
+    obs = cpu(t["obs"])
+    np.testing.assert_allclose(obs[..., 3], cpu(out[5]) / 10, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(obs[..., 0], cpu(out[1]) / 10, rtol=1e-6)
+
+
+def test_sarl_facade_and_philox():
+    from ris_vec_marl_amd import SarlEnviron, reference_lanes, sarl_action_map, sarl_observe
+    L = reference_lanes()
+    V, M = 8, 40
+    env = SarlEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3,
+                      device="cuda:0", seed=77)
+    env.make_new_game(); env.renew_positions(); env.compute_parms()
+    assert (env.t_factor1, env.t_factor2, env.penalty1, env.penalty2) == (1, 0.6, 2, 2)
+    B0 = env.DataBuf.copy()
+    rng = np.random.default_rng(0)
+    power, phase = rng.uniform(0, 1, (2, V)), rng.uniform(0, 2 * np.pi, M)
+    r = env.step(power, phase)
+    assert len(r) == 6 and isinstance(r[0], float) and r[1].shape == (V,)
+    gain = env.channel_gains
+    o = orc.sarl_step(B0[None], gain[None], power[None], np.zeros((1, V)), orc.SarlParams())
+    arr = np.rint(r[1] - o["data_buf"][0])                    # Philox arrivals are integers (kbit each)
+    want = orc.philox_arrivals(np.arange(1), V, 0, 77, 3.0)[0]
+    assert np.array_equal(arr, want)
+    np.testing.assert_allclose(r[2], o["data_t"][0], rtol=2e-5, atol=1e-7)
+    # batched marshalling helpers
+    act = torch.from_numpy(rng.uniform(-1.2, 1.2, (5, 2 * V + M)).astype(np.float32)).cuda()
+    pw, ph = sarl_action_map(act, V, M)
+    pw_ref, ph_ref = orc.sarl_action_map(cpu(act).astype(np.float64), V, M)
+    # (clip(x) + 1) / 2 in float32: the +1 cancels against -0.999, absolute error 1 ulp(1) = 6e-8
+    np.testing.assert_allclose(cpu(pw), pw_ref, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(cpu(ph), ph_ref, rtol=1e-6, atol=1e-6)
+    venv = make_vec(5, V, M)
+    venv.make_new_game(); venv.compute_parms()
+    o6 = venv.sarl_step(pw, ph)
+    ob = sarl_observe(venv, ph)
+    ref = orc.sarl_obs(cpu(ph).astype(np.float64), cpu(o6[1]), cpu(o6[2]), cpu(o6[3]), cpu(o6[5]), cpu(venv.tensors["rate"]))
+    np.testing.assert_allclose(cpu(ob), ref, rtol=2e-6, atol=1e-8)

@@ -170,3 +170,21 @@ def test_poisson_sampler_statistics():
         n = a.size
         assert abs(a.mean() - lam) < 5 * np.sqrt(lam / n)
         assert abs(a.var() - lam) < 0.05 * lam
+
+
+@pytest.mark.parametrize("name", ["sarl_step_8_40", "sarl_step_4_16"])
+def test_sarl_step(name):
+    """f1: Simulation-SARL/Environment.py step(action_power, action_phase)."""
+    g = load(name + ".npz")
+    M = g["theta"].shape[1]
+    # get_next_phase (SENV:133-139) and the cascaded gain of compute_data_rate (SENV:149-157)
+    theta = np.cos(g["action_phase"]) + 1j * np.sin(g["action_phase"])
+    close(theta, g["theta"], rtol=0, atol=1e-15)
+    dist, _, h_r = orc.geometry(g["pos"], M)
+    close(h_r, g["h_r"], rtol=0, atol=2e-13)
+    gain = orc.gain_free(theta, h_r, orc.phase_R(M), dist)
+    o = orc.sarl_step(g["data_buf0"], gain, g["action_power"], g["arrivals"], orc.SarlParams())
+    for k in ("reward_mean", "data_buf", "data_t", "data_p", "over_power", "over_data", "vehicle_rate"):
+        close(o[k], g[k], rtol=1e-10, atol=1e-13)
+    # both branches of the overload logic are exercised
+    assert (g["over_data"] > 0).any() and (g["over_data"] == 0).any() and (g["over_data"] > 2).any()

@@ -403,6 +403,52 @@ def capture_trajectory(V, M, n_ep, n_step, refresh_every, bcd_every, seed, which
     return res
 
 
+def capture_sarl(V, M, n, seed):
+    """f1: Simulation-SARL/Environment.py step(action_power, action_phase) (SENV:321-359)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sarl_reference_env", "/root/reference/Simulation-SARL/Environment.py")
+    SREF = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(SREF)            # NB the module seeds np.random(1234) at import (SENV:7)
+    np.random.seed(seed); random.seed(seed)
+    rng = np.random.default_rng(seed)
+    L = lanes()
+    env = SREF.Environ(L["down"], L["up"], L["left"], L["right"], 400, 400, V, M, 3)
+    env.make_new_game()
+    rec = {k: [] for k in ("pos", "data_buf0", "action_power", "action_phase", "arrivals", "theta", "h_r", "dist",
+                           "reward_mean", "data_buf", "data_t", "data_p", "over_power", "over_data", "vehicle_rate")}
+    for i in range(n):
+        if i % 16 == 0:
+            for _ in range(int(rng.integers(1, 40))):
+                env.renew_positions()
+            env.compute_parms()
+        mode = i % 4
+        B0 = rng.uniform(0.0, 12.0, V)
+        if mode == 1:
+            B0 = rng.uniform(0.0, 0.6, V)                 # drained buffers: over_data / over_power branch
+        if mode == 2:
+            B0 = rng.uniform(2.0, 3.5, V)
+        power = rng.uniform(0.0, 1.0, (2, V))
+        if mode == 3:
+            power[1] = rng.uniform(0.0, 0.05, V)          # weak local CPU
+        phase = rng.uniform(0.0, 2 * np.pi, M)
+        env.DataBuf = B0.copy()
+        with Recorder() as r:
+            out = env.step(power.copy(), phase.copy())
+        arr = np.array(r.values("poisson"), dtype=np.int64)
+        assert len(arr) == V
+        rec["pos"].append(vehicles_state(env)[0]); rec["data_buf0"].append(B0); rec["action_power"].append(power)
+        rec["action_phase"].append(phase); rec["arrivals"].append(arr)
+        rec["theta"].append(np.array(env.elements_phase_shift_complex, dtype=complex))
+        rec["h_r"].append(env.phases_R_i.copy()); rec["dist"].append(env.distances_R_i.copy())
+        rec["reward_mean"].append(float(out[0])); rec["data_buf"].append(np.array(out[1]))
+        rec["data_t"].append(np.array(out[2])); rec["data_p"].append(np.array(out[3]))
+        rec["over_power"].append(np.array(out[4])); rec["over_data"].append(np.array(out[5]))
+        rec["vehicle_rate"].append(env.vehicle_rate.copy())
+    res = {k: np.array(v) for k, v in rec.items()}
+    res["b"] = env.phase_R.copy()
+    return res
+
+
 def save(name, d):
     path = os.path.join(OUT_DIR, name)
     np.savez_compressed(path, **d)
@@ -425,6 +471,8 @@ def main():
         for which in ("default", "yaml"):
             save("step_%d_%s.npz" % (V, which), capture_step(V, 384, 600 + V, which))
     save("trajectory_8_36.npz", capture_trajectory(8, 36, 7, 40, 5, 100, 900))
+    save("sarl_step_8_40.npz", capture_sarl(8, 40, 192, 1100))
+    save("sarl_step_4_16.npz", capture_sarl(4, 16, 128, 1101))
 
 
 if __name__ == "__main__":
