@@ -760,3 +760,49 @@ def test_sarl_facade_and_philox():
     ob = sarl_observe(venv, ph)
     ref = orc.sarl_obs(cpu(ph).astype(np.float64), cpu(o6[1]), cpu(o6[2]), cpu(o6[3]), cpu(o6[5]), cpu(venv.tensors["rate"]))
     np.testing.assert_allclose(cpu(ob), ref, rtol=2e-6, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------- edge shapes
+@pytest.mark.parametrize("E,V,M,b", [(1, 1, 1, 0), (1, 1, 2, 1), (3, 2, 2, 2), (65, 64, 2, 3), (2, 7, 3, 3),
+                                     (129, 8, 64, 3), (31, 16, 256, 3), (5, 4, 16, 6)])
+def test_edge_shapes_full_protocol(E, V, M, b):
+    """Smallest / largest / ragged shapes through every kernel: reset, mobility, geometry, random phase,
+    BCD, gains (fused and not), step - against the oracle on the device's own float32 tensors.
+    E is deliberately not a multiple of the envs a wave owns."""
+    rng = np.random.default_rng(E * 1000 + V * 10 + M)
+    p = orc.OracleParams.yaml_effective()
+    env = make_vec(E, V, M, b=b, seed=9, yaml=True)
+    env.make_new_game()
+    for _ in range(2):
+        env.renew_positions()
+    env.compute_parms()
+    t = env.tensors
+    dist, ang, h_r = orc.geometry(cpu(t["pos"]), M)
+    np.testing.assert_allclose(c128(t["h_r"]), h_r, rtol=0, atol=1.2e-7)
+    env.Random_phase()
+    th0 = c128(t["theta"])
+    idx = cpu(env.optimize_phase_shift(return_idx=True))
+    o_th, o_idx = orc.bcd_sweep(th0, c128(t["h_r"]), c128(t["b"]), dist, b)
+    gap = orc.bcd_margin(th0, c128(t["h_r"]), c128(t["b"]), b)
+    safe = np.minimum.accumulate(gap, axis=1) > 1e-9
+    assert np.array_equal(idx[safe], o_idx[safe])
+    B0 = cpu(t["data_buf"]).astype(np.float64)
+    action, partner, ng, arrivals = random_step_inputs(E, V, rng)
+    action = action.astype(np.float32)
+    out = env.step(action, partner.astype(np.int32), ng.astype(np.int32), arrivals.astype(np.int32), fused=True)
+    img = np.einsum("em,evm,m->ev", c128(t["theta"]), c128(t["h_r"]), c128(t["b"]))
+    pl = cpu(t["pl"]).astype(np.float64)
+    g_dev = cpu(t["gain"]).astype(np.float64)
+    assert (np.abs(g_dev - pl * np.abs(img) ** 2) <= 3e-6 * pl * np.abs(img) ** 2 + pl * 2 * np.abs(img) * (3 * 6e-8 * M)).all()
+    o = orc.step(B0, np.zeros(E), g_dev, action.astype(np.float64), partner, ng, arrivals, p)
+    near_qos, near_other = step_mask(o, partner, g_dev, np.zeros(E))
+    check_step(env, out, o, B0, p, near_qos, near_other)
+    # cached-gain step on a second env gives the same answer as the fused one
+    env2 = make_vec(E, V, M, b=b, seed=9, yaml=True)
+    t2 = env2.tensors
+    for k in ("h_r", "theta", "pl"):
+        t2[k].copy_(t[k])
+    t2["data_buf"].copy_(torch.from_numpy(B0.astype(np.float32)))
+    env2.update_channel_gains()
+    out2 = env2.step(action, partner.astype(np.int32), ng.astype(np.int32), arrivals.astype(np.int32), fused=False)
+    assert np.isclose(cpu(out2[2]), cpu(out[2]), rtol=1e-5, atol=1e-5).all()
