@@ -58,11 +58,16 @@ enum {
     RISVEC_STEP_POLICY_ACTION = 4,  /* `action` is the policy output [E,V,2] in [-1,1]; apply
                                        marl_train_bcd.py:1601-1608 in-kernel             */
     RISVEC_STEP_OBS = 8,            /* write obs[E,V,5] (marl_train_bcd.py:819-827)        */
-    RISVEC_STEP_REUSE_COLSUM = 16   /* risvec_step_fused_bcd: c_col is current, skip its rebuild */
+    RISVEC_STEP_REUSE_COLSUM = 16,  /* risvec_step_fused_bcd: c_col is current, skip its rebuild */
+    RISVEC_STEP_REUSE_SSUM = 32     /* risvec_step_fused_bcd: s_sum is current (see RISVEC_BCD_REUSE_SSUM) */
 };
 
 /* risvec_bcd flags */
-enum { RISVEC_BCD_REUSE_COLSUM = 1 };  /* caller guarantees c_col matches h_r and b */
+enum {
+    RISVEC_BCD_REUSE_COLSUM = 1,   /* caller guarantees c_col matches h_r and b */
+    RISVEC_BCD_REUSE_SSUM = 2      /* caller guarantees theta and c_col are unchanged since the last sweep
+                                      wrote s_sum: start from it instead of re-summing theta.c */
+};
 
 /* Physics / geometry parameters: the attributes of `Environ` that the driver sets
  * (ENV:57-190, overridden by marl_train_bcd.py:548-779).  Passed by value to kernels. */
@@ -144,6 +149,7 @@ typedef struct RisVecState {
     float *power_w;         /* [E,2,V] last_power_W (may be NULL unless flag set)     */
     /* BCD cache: c[e,m] = (sum_v h_r[e,v,m]) * b[m] in float64 (pure geometry, like `pl`) */
     double *c_col;          /* [E,M]   c128; written by risvec_geometry / risvec_colsum */
+    double *s_sum;          /* [E]     c128; S = sum_m theta_m c_m left by the last BCD sweep (may be NULL) */
     /* SARL variant only (Simulation-SARL/Environment.py:337-340); the MARL step never writes it */
     float *over_data;       /* [E,V]   (may be NULL for MARL-only use)                 */
 } RisVecState;

@@ -21,7 +21,8 @@ OK, ERR_ARG, ERR_SHAPE, ERR_LAUNCH, ERR_UNSUPPORTED = range(5)
 DIR_U, DIR_D, DIR_L, DIR_R = range(4)
 CH_FREE, CH_3GPP_UMI, CH_3GPP_UMA, CH_OTHER = range(4)
 STEP_METRICS, STEP_POWER_W, STEP_POLICY_ACTION, STEP_OBS, STEP_REUSE_COLSUM = 1, 2, 4, 8, 16
-BCD_REUSE_COLSUM = 1
+STEP_REUSE_SSUM = 32
+BCD_REUSE_COLSUM, BCD_REUSE_SSUM = 1, 2
 
 METRIC_NAMES = (
     "global_reward", "last_off_kbit_sum", "last_local_kbit_sum", "last_mec_queue_cycles",
@@ -64,7 +65,7 @@ class RisVecState(C.Structure):
         ("theta", _FP), ("b", _FP), ("h_d", _FP), ("gain", _FP),
         ("data_buf", _FP), ("mec_q", _FP),
         ("rate", _FP), ("data_t", _FP), ("data_p", _FP), ("reward", _FP), ("over_power", _FP),
-        ("obs", _FP), ("metrics", _FP), ("power_w", _FP), ("c_col", _FP), ("over_data", _FP),
+        ("obs", _FP), ("metrics", _FP), ("power_w", _FP), ("c_col", _FP), ("s_sum", _FP), ("over_data", _FP),
     ]
 
 

@@ -63,6 +63,29 @@ __device__ __forceinline__ int pick_candidate(double qr, double qi, const double
     }
 }
 
+// theta lives in HBM as complex64, but the reference keeps it as complex128 holding the EXACT
+// candidate phasors (ENV:213-220).  When a stored element is the float32 image of a candidate,
+// the sweep uses that candidate in float64 - so S = sum theta.c stays what the reference's is,
+// and the sum a sweep leaves behind is exactly the sum of what it stored.  Anything else
+// (arbitrary phases from get_next_phase, the all-zero start) is used as stored.
+template <int NC>
+__device__ __forceinline__ void snap_theta(float2 t, const double2* __restrict__ cand, double& tr, double& ti) {
+    if constexpr (NC == 8) {
+        // only the four diagonal phasors are inexact in float32 (+-1, +-j and 0 are exact)
+        const float r32 = 0.70710677f;
+        const double r64 = 0.70710678118654757;
+        const bool diag = fabsf(t.x) == r32 && fabsf(t.y) == r32;
+        tr = diag ? copysign(r64, (double)t.x) : (double)t.x;
+        ti = diag ? copysign(r64, (double)t.y) : (double)t.y;
+    } else {
+        double cr, ci;
+        pick_candidate<NC>((double)t.x, -(double)t.y, cand, cr, ci);  // nearest candidate: max Re(conj(cand) t)
+        const bool is_cand = (float)cr == t.x && (float)ci == t.y;
+        tr = is_cand ? cr : (double)t.x;
+        ti = is_cand ? ci : (double)t.y;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // k_colsum
 // ---------------------------------------------------------------------------
@@ -136,79 +159,122 @@ k_colsum(Dims d, const float* __restrict__ h_r, const float* __restrict__ b, dou
 // ---------------------------------------------------------------------------
 // k_bcd_sweep
 // ---------------------------------------------------------------------------
-constexpr int kSweepBlk = 16;   // elements per register block (two 128-byte lines of c): long enough that the
-                                // next block's loads land while this block's 16 chain steps run
+// A wave owns 64 envs, one lane each.  The rows a lane walks (c[e,:] and theta[e,:]) are 4 KiB
+// and 2 KiB apart between lanes, so a per-lane load would touch 64 cache lines per instruction;
+// measured, that - not the chain - bounded the kernel (fewer envs per wave made it slower).  So
+// tiles move COOPERATIVELY: 8 lanes read one env's 128-byte line, an instruction covers 8 envs
+// with full lines, the tile is transposed through LDS, and each lane then reads its own row from
+// LDS.  New theta goes back the same way.  The next tile's global loads are issued before the
+// current tile's 8 chain steps, so they land underneath them.
+constexpr int kSweepBlk = 8;                                // elements per tile (128 B of c, 64 B of theta per env);
+                                                            // 16 would need >256 VGPRs (measured: spills, 3x slower)
+constexpr int kCRow = kSweepBlk + 1;                        // LDS row strides (in elements): +1 keeps the
+constexpr int kTRow = kSweepBlk + 2;                        // 16-lane read groups on distinct banks
 
 template <int NC>
 __global__ void __launch_bounds__(kWave)
 k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
-            int32_t* __restrict__ idx_out) {
+            int32_t* __restrict__ idx_out, double* __restrict__ s_sum, int reuse_s) {
     __shared__ double2 s_cand[NC];
+    __shared__ double2 s_c[kWave * kCRow];                  // 9 216 B
+    __shared__ float2 s_t[kWave * kTRow];                   // 5 120 B
     const int M = d.M;
-    const int tid = threadIdx.x;
-    if (tid < NC) {                              // candidate k: exp(j 2 pi k / NC)  (ENV:169, 213)
+    const int lane = threadIdx.x;
+    if (lane < NC) {                             // candidate k: exp(j 2 pi k / NC)  (ENV:169, 213)
         double s, c;
-        sincospi(2.0 * (double)tid / (double)NC, &s, &c);
-        s_cand[tid] = make_double2(c, s);
+        sincospi(2.0 * (double)lane / (double)NC, &s, &c);
+        s_cand[lane] = make_double2(c, s);
     }
     __syncthreads();
-    const long long e_raw = (long long)blockIdx.x * kWave + tid;
-    const bool live = e_raw < d.E;
-    const long long e = live ? e_raw : d.E - 1;   // idle lanes shadow the last env, never store
-    const double2* __restrict__ c = reinterpret_cast<const double2*>(c_col) + e * M;
-    float2* __restrict__ th = reinterpret_cast<float2*>(theta) + e * M;
+    const long long e0 = (long long)blockIdx.x * kWave;
+    const long long e_last = d.E - 1;
+    const bool live = e0 + lane < d.E;
+    const long long e = live ? e0 + lane : e_last;
+    const double2* __restrict__ cg = reinterpret_cast<const double2*>(c_col);
+    float2* __restrict__ tg = reinterpret_cast<float2*>(theta);
     const int n_blk = (M + kSweepBlk - 1) / kSweepBlk;
-    const int m_last = M - 1;
+    // cooperative roles: for c, 8 lanes x 16 B cover one env's 128-byte line (8 envs per
+    // instruction); for theta, 4 lanes x 16 B cover one env's 64 bytes (16 envs per instruction)
+    const int sub = lane >> 3, q = lane & 7;
+    const int sub4 = lane >> 2, q4 = lane & 3;
 
-    double2 cc[kSweepBlk], cn[kSweepBlk];
-    float2 tc[kSweepBlk], tn[kSweepBlk];
-
-    // ---- pass 1: S = sum_m theta_m c_m in a fixed order (deterministic), two chains
-    double Sr = 0.0, Si = 0.0, Tr = 0.0, Ti = 0.0;
+    // cooperative tile fetch into registers; clamped indices keep every address valid
+    double2 pc[8];
+    float4 pt[4];
+    auto fetch = [&](int kb) {
 #pragma unroll
-    for (int j = 0; j < kSweepBlk; ++j) { cc[j] = c[min(j, m_last)]; tc[j] = th[min(j, m_last)]; }
-    for (int kb = 0; kb < n_blk; ++kb) {
-#pragma unroll
-        for (int j = 0; j < kSweepBlk; ++j) {
-            const int m = min((kb + 1) * kSweepBlk + j, m_last);
-            cn[j] = c[m]; tn[j] = th[m];
+        for (int i = 0; i < 8; ++i) {
+            const long long ee = min(e0 + i * 8 + sub, e_last);
+            const int m = min(kb * kSweepBlk + q, M - 1);
+            pc[i] = cg[ee * M + m];
         }
 #pragma unroll
-        for (int j = 0; j < kSweepBlk; j += 2) {
-            const int m = kb * kSweepBlk + j;
-            if (m < M) {
-                Sr += (double)tc[j].x * cc[j].x - (double)tc[j].y * cc[j].y;
-                Si += (double)tc[j].x * cc[j].y + (double)tc[j].y * cc[j].x;
-            }
-            if (m + 1 < M) {
-                Tr += (double)tc[j + 1].x * cc[j + 1].x - (double)tc[j + 1].y * cc[j + 1].y;
-                Ti += (double)tc[j + 1].x * cc[j + 1].y + (double)tc[j + 1].y * cc[j + 1].x;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kSweepBlk; ++j) { cc[j] = cn[j]; tc[j] = tn[j]; }
-    }
-    Sr += Tr; Si += Ti;
-
-    // ---- pass 2: the chain.  Elements past M (tail of the last block) are fed as c = theta = 0,
-    // for which a step leaves S unchanged, so the chain needs no masking.  The "no candidate
-    // scores above 0" case (new S exactly 0; ENV:211, 220) is kept OFF the dependent chain: a
-    // block first runs without it while OR-ing a flag, and is re-run exactly from its saved
-    // start state in the (practically never taken) case that some lane raised the flag.
-    auto load_blk = [&](int kb, double2 (&cb)[kSweepBlk], float2 (&tb)[kSweepBlk]) {
-#pragma unroll
-        for (int j = 0; j < kSweepBlk; ++j) {
-            const int m = kb * kSweepBlk + j;
-            const double2 cv = c[min(m, m_last)];
-            const float2 tv = th[min(m, m_last)];
-            const bool ok = m < M;
-            cb[j] = make_double2(ok ? cv.x : 0.0, ok ? cv.y : 0.0);
-            tb[j] = make_float2(ok ? tv.x : 0.f, ok ? tv.y : 0.f);
+        for (int i = 0; i < 4; ++i) {
+            const long long ee = min(e0 + i * 16 + sub4, e_last);
+            const int m0 = kb * kSweepBlk + 2 * q4;
+            const float2 a = tg[ee * M + min(m0, M - 1)], b2 = tg[ee * M + min(m0 + 1, M - 1)];
+            pt[i] = make_float4(a.x, a.y, b2.x, b2.y);
         }
     };
-    load_blk(0, cc, tc);
+    // registers -> LDS tile (transposition), then each lane takes its own row
+    auto stage = [&](int kb, double2 (&cc)[kSweepBlk], float2 (&tc)[kSweepBlk]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_c[(i * 8 + sub) * kCRow + q] = pc[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s_t[(i * 16 + sub4) * kTRow + 2 * q4] = make_float2(pt[i].x, pt[i].y);
+            s_t[(i * 16 + sub4) * kTRow + 2 * q4 + 1] = make_float2(pt[i].z, pt[i].w);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < kSweepBlk; ++j) {
+            const bool ok = kb * kSweepBlk + j < M;         // past M: c = theta = 0, a no-op for the chain
+            const double2 cv = s_c[lane * kCRow + j];
+            const float2 tv = s_t[lane * kTRow + j];
+            cc[j] = make_double2(ok ? cv.x : 0.0, ok ? cv.y : 0.0);
+            tc[j] = make_float2(ok ? tv.x : 0.f, ok ? tv.y : 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    double2 cc[kSweepBlk];
+    float2 tc[kSweepBlk];
+
+    // ---- pass 1: S = sum_m theta_m c_m in a fixed order (deterministic), two chains.  A sweep
+    // ends knowing exactly this sum for the theta it wrote, and leaves it in s_sum[e]: the next
+    // sweep of an unchanged (theta, c) starts from there and skips the pass.
+    double Sr = 0.0, Si = 0.0, Tr = 0.0, Ti = 0.0;
+    if (reuse_s) {
+        const double2 s0 = reinterpret_cast<const double2*>(s_sum)[e];
+        Sr = s0.x; Si = s0.y;
+    } else {
+        fetch(0);
+        for (int kb = 0; kb < n_blk; ++kb) {
+            stage(kb, cc, tc);
+            fetch(kb + 1);                                  // clamped past the end: harmless re-read
+#pragma unroll
+            for (int j = 0; j < kSweepBlk; j += 2) {
+                double ar, ai, br, bi;
+                snap_theta<NC>(tc[j], s_cand, ar, ai);
+                snap_theta<NC>(tc[j + 1], s_cand, br, bi);
+                Sr += ar * cc[j].x - ai * cc[j].y;
+                Si += ar * cc[j].y + ai * cc[j].x;
+                Tr += br * cc[j + 1].x - bi * cc[j + 1].y;
+                Ti += br * cc[j + 1].y + bi * cc[j + 1].x;
+            }
+        }
+        Sr += Tr; Si += Ti;
+    }
+
+    // ---- pass 2: the chain.  Elements past M are fed as c = theta = 0, for which a step leaves S
+    // unchanged, so the chain needs no masking.  The "no candidate scores above 0" case (new S
+    // exactly 0; ENV:211, 220) is kept OFF the dependent chain: a tile first runs without it
+    // while OR-ing a flag, and is re-run exactly from its saved start state in the (practically
+    // never taken) case that some lane raised the flag.
+    fetch(0);
     for (int kb = 0; kb < n_blk; ++kb) {
-        load_blk(kb + 1, cn, tn);
+        stage(kb, cc, tc);
+        fetch(kb + 1);
         float2 out[kSweepBlk];
         int ko[kSweepBlk];
         const double Sr0 = Sr, Si0 = Si;
@@ -216,7 +282,8 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
 #pragma unroll
         for (int j = 0; j < kSweepBlk; ++j) {
             const double2 cm = cc[j];
-            const double tr = tc[j].x, ti = tc[j].y;
+            double tr, ti;
+            snap_theta<NC>(tc[j], s_cand, tr, ti);              // off the dependent chain
             const double rr = Sr - (tr * cm.x - ti * cm.y);
             const double ri = Si - (tr * cm.y + ti * cm.x);
             const double qr = rr * cm.x + ri * cm.y;            // q = conj(rest) * c_m
@@ -233,7 +300,8 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
 #pragma unroll
             for (int j = 0; j < kSweepBlk; ++j) {        // unrolled: cc/out/ko must stay in registers
                 const double2 cm = cc[j];
-                const double tr = tc[j].x, ti = tc[j].y;
+                double tr, ti;
+                snap_theta<NC>(tc[j], s_cand, tr, ti);
                 const double rr = Sr - (tr * cm.x - ti * cm.y);
                 const double ri = Si - (tr * cm.y + ti * cm.x);
                 double nr, ni;
@@ -247,19 +315,30 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
                 ko[j] = none ? -1 : kk;
             }
         }
-        if (live) {
+        // new theta: lane rows -> LDS -> cooperative stores (16 envs x 64 contiguous bytes each)
+#pragma unroll
+        for (int j = 0; j < kSweepBlk; ++j) s_t[lane * kTRow + j] = out[j];
+        if (idx_out && live) {
 #pragma unroll
             for (int j = 0; j < kSweepBlk; ++j) {
                 const int m = kb * kSweepBlk + j;
-                if (m < M) {
-                    th[m] = out[j];
-                    if (idx_out) idx_out[e * M + m] = ko[j];
-                }
+                if (m < M) idx_out[e * M + m] = ko[j];
             }
         }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < kSweepBlk; ++j) { cc[j] = cn[j]; tc[j] = tn[j]; }
+        for (int i = 0; i < 4; ++i) {
+            const long long ee = e0 + i * 16 + sub4;
+            const int m0 = kb * kSweepBlk + 2 * q4;
+            const float2 a = s_t[(i * 16 + sub4) * kTRow + 2 * q4], b2 = s_t[(i * 16 + sub4) * kTRow + 2 * q4 + 1];
+            if (ee < d.E) {
+                if (m0 < M) tg[ee * M + m0] = a;
+                if (m0 + 1 < M) tg[ee * M + m0 + 1] = b2;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
+    if (live && s_sum) reinterpret_cast<double2*>(s_sum)[e] = make_double2(Sr, Si);
 }
 
 // ---------------------------------------------------------------------------
@@ -275,26 +354,27 @@ hipError_t launch_colsum(const RisVecState& s, hipStream_t st) {
 }
 
 template <int NC>
-static hipError_t launch_sweep_nc(const RisVecState& s, int32_t* idx_out, hipStream_t st) {
+static hipError_t launch_sweep_nc(const RisVecState& s, int32_t* idx_out, bool reuse_s, hipStream_t st) {
     const unsigned grid = (unsigned)((s.n_envs + kWave - 1) / kWave);
-    hipLaunchKernelGGL((k_bcd_sweep<NC>), dim3(grid), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out);
+    hipLaunchKernelGGL((k_bcd_sweep<NC>), dim3(grid), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out,
+                       s.s_sum, (reuse_s && s.s_sum) ? 1 : 0);
     return hipGetLastError();
 }
 
 hipError_t launch_bcd(const RisVecState& s, const RisVecParams&, int32_t* idx_out, bool reuse_colsum,
-                      hipStream_t st) {
+                      bool reuse_s, hipStream_t st) {
     if (!reuse_colsum) {
         const hipError_t err = launch_colsum(s, st);
         if (err != hipSuccess) return err;
     }
     switch (s.control_bit) {
-        case 0: return launch_sweep_nc<1>(s, idx_out, st);
-        case 1: return launch_sweep_nc<2>(s, idx_out, st);
-        case 2: return launch_sweep_nc<4>(s, idx_out, st);
-        case 3: return launch_sweep_nc<8>(s, idx_out, st);
-        case 4: return launch_sweep_nc<16>(s, idx_out, st);
-        case 5: return launch_sweep_nc<32>(s, idx_out, st);
-        case 6: return launch_sweep_nc<64>(s, idx_out, st);
+        case 0: return launch_sweep_nc<1>(s, idx_out, reuse_s, st);
+        case 1: return launch_sweep_nc<2>(s, idx_out, reuse_s, st);
+        case 2: return launch_sweep_nc<4>(s, idx_out, reuse_s, st);
+        case 3: return launch_sweep_nc<8>(s, idx_out, reuse_s, st);
+        case 4: return launch_sweep_nc<16>(s, idx_out, reuse_s, st);
+        case 5: return launch_sweep_nc<32>(s, idx_out, reuse_s, st);
+        case 6: return launch_sweep_nc<64>(s, idx_out, reuse_s, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -304,10 +384,11 @@ hipError_t launch_step_fused_bcd(const RisVecState& s, const RisVecParams& p, co
                                  const int32_t* partner, const int32_t* n_groups,
                                  const int32_t* arrivals, uint64_t seed, uint32_t counter,
                                  uint32_t flags, hipStream_t st) {
-    hipError_t err = launch_bcd(s, p, nullptr, (flags & RISVEC_STEP_REUSE_COLSUM) != 0, st);
+    hipError_t err = launch_bcd(s, p, nullptr, (flags & RISVEC_STEP_REUSE_COLSUM) != 0,
+                                (flags & RISVEC_STEP_REUSE_SSUM) != 0, st);
     if (err != hipSuccess) return err;
     return launch_step(s, p, action, partner, n_groups, arrivals, seed, counter,
-                       flags & ~(uint32_t)RISVEC_STEP_REUSE_COLSUM, true, st);
+                       flags & ~(uint32_t)(RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM), true, st);
 }
 
 }  // namespace risvec

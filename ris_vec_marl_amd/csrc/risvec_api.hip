@@ -73,7 +73,7 @@ int check_step(const char* fn, const RisVecState* s, const float* action, const 
     if (flags & RISVEC_STEP_OBS) REQ_PTR(s->obs, "state.obs");
     if (flags & RISVEC_STEP_POWER_W) REQ_PTR(s->power_w, "state.power_w");
     if (flags & ~(uint32_t)(RISVEC_STEP_METRICS | RISVEC_STEP_POWER_W | RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS |
-                            RISVEC_STEP_REUSE_COLSUM))
+                            RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM))
         return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
     if (fused) {
         REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->b, "state.b");
@@ -209,8 +209,13 @@ int risvec_bcd(const RisVecState* s, const RisVecParams* p, int32_t* idx_out, ui
     REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->b, "state.b");
     REQ_PTR(s->c_col, "state.c_col");
     OPT_PTR(idx_out, "idx_out");
-    if (flags & ~(uint32_t)RISVEC_BCD_REUSE_COLSUM) return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
-    return finish(fn, risvec::launch_bcd(*s, *p, idx_out, (flags & RISVEC_BCD_REUSE_COLSUM) != 0, (hipStream_t)stream));
+    OPT_PTR(s->s_sum, "state.s_sum");
+    if (flags & ~(uint32_t)(RISVEC_BCD_REUSE_COLSUM | RISVEC_BCD_REUSE_SSUM))
+        return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
+    if ((flags & RISVEC_BCD_REUSE_SSUM) && !s->s_sum)
+        return fail(RISVEC_ERR_ARG, "%s: RISVEC_BCD_REUSE_SSUM needs state.s_sum", fn);
+    return finish(fn, risvec::launch_bcd(*s, *p, idx_out, (flags & RISVEC_BCD_REUSE_COLSUM) != 0,
+                                         (flags & RISVEC_BCD_REUSE_SSUM) != 0, (hipStream_t)stream));
 }
 
 int risvec_set_phase(const RisVecState* s, const float* angle, risvec_stream_t stream) {

@@ -91,6 +91,8 @@ class VecEnviron(ParamAttrs):
         self._chan = 0           # 3GPP-gain / random-phase counter
         self._t: Dict[str, torch.Tensor] = {}
         self._colsum_valid = False     # c_col matches h_r (set by compute_parms / rebuild_colsum)
+        self._ssum_sweeps = 0          # >0: s_sum = sum theta.c of the CURRENT theta, left by that many
+                                       # consecutive sweeps (0 = unknown; refreshed every 64 sweeps)
         self._cstate: Optional[N.RisVecState] = None
         self._cparams: Optional[N.RisVecParams] = None
         self._cparams_version = -1
@@ -130,6 +132,7 @@ class VecEnviron(ParamAttrs):
         t["metrics"] = z(E, N.METRICS)
         t["power_w"] = z(E, 2, V)
         t["c_col"] = z(E, M, 2, dt=torch.float64)      # BCD column sums (sum_v h_r) * b, f64
+        t["s_sum"] = z(E, 2, dt=torch.float64)         # sum_m theta_m c_m left by the last sweep
         s = N.RisVecState()
         s.abi_version = N.ABI_VERSION
         s.struct_bytes = C.sizeof(N.RisVecState)
@@ -137,7 +140,7 @@ class VecEnviron(ParamAttrs):
         s.env_offset = self.env_offset
         for k in ("pos", "dir", "vel", "dist_r", "ang_r", "pl", "h_r", "theta", "b", "gain", "data_buf",
                   "mec_q", "rate", "data_t", "data_p", "reward", "over_power", "obs", "metrics", "power_w", "c_col",
-                  "over_data"):
+                  "s_sum", "over_data"):
             setattr(s, k, t[k].data_ptr())
         s.h_d = None
         self._cstate = s
@@ -223,6 +226,7 @@ class VecEnviron(ParamAttrs):
         self._ensure_device()
         N.check(N.load().risvec_geometry(C.byref(self._cstate), C.byref(self._p()), self._stream()))
         self._colsum_valid = True
+        self._ssum_sweeps = 0
 
     def rebuild_colsum(self) -> None:
         """Recompute the BCD cache c_col[e,m] = (sum_v h_r[e,v,m]) b[m] (float64).  compute_parms()
@@ -230,10 +234,25 @@ class VecEnviron(ParamAttrs):
         self._ensure_device()
         N.check(N.load().risvec_colsum(C.byref(self._cstate), self._stream()))
         self._colsum_valid = True
+        self._ssum_sweeps = 0
 
     def invalidate_colsum(self) -> None:
-        """Tell the env that h_r was modified behind its back: the next BCD rebuilds c_col."""
+        """Tell the env that h_r or theta was modified behind its back (a direct write to
+        `tensors[...]`): the next BCD rebuilds c_col and re-sums theta.c."""
         self._colsum_valid = False
+        self._ssum_sweeps = 0
+
+    def _bcd_flags(self, reuse_colsum: Optional[bool], step: bool) -> int:
+        reuse_c = self._colsum_valid if reuse_colsum is None else bool(reuse_colsum)
+        reuse_s = reuse_c and 0 < self._ssum_sweeps < 64
+        if step:
+            return (N.STEP_REUSE_COLSUM if reuse_c else 0) | (N.STEP_REUSE_SSUM if reuse_s else 0)
+        return (N.BCD_REUSE_COLSUM if reuse_c else 0) | (N.BCD_REUSE_SSUM if reuse_s else 0)
+
+    def _bcd_done(self, flags: int, step: bool) -> None:
+        reused_s = bool(flags & (N.STEP_REUSE_SSUM if step else N.BCD_REUSE_SSUM))
+        self._colsum_valid = True
+        self._ssum_sweeps = self._ssum_sweeps + 1 if reused_s else 1
 
     def optimize_phase_shift(self, return_idx: bool = False, reuse_colsum: Optional[bool] = None):
         """Environment.py:208-220 (one BCD sweep, objective of :222-231).  The column sums the
@@ -241,10 +260,9 @@ class VecEnviron(ParamAttrs):
         compute_parms()/rebuild_colsum()), otherwise rebuilt first.  reuse_colsum overrides."""
         self._ensure_device()
         idx = torch.zeros(self.n_envs, self.M, dtype=torch.int32, device=self.device) if return_idx else None
-        reuse = self._colsum_valid if reuse_colsum is None else bool(reuse_colsum)
-        N.check(N.load().risvec_bcd(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(idx),
-                                    N.BCD_REUSE_COLSUM if reuse else 0, self._stream()))
-        self._colsum_valid = True
+        flags = self._bcd_flags(reuse_colsum, step=False)
+        N.check(N.load().risvec_bcd(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(idx), flags, self._stream()))
+        self._bcd_done(flags, step=False)
         return idx
 
     def update_channel_gains(self, u_los=None, z_shadow=None, small=None) -> None:
@@ -273,6 +291,7 @@ class VecEnviron(ParamAttrs):
         self._ensure_device()
         a = self._arg(action_phase, torch.float32, (self.n_envs, self.M), "action_phase")
         N.check(N.load().risvec_set_phase(C.byref(self._cstate), _dev_ptr(a), self._stream()))
+        self._ssum_sweeps = 0
 
     def Random_phase(self, idx=None) -> None:
         """Environment.py:203-206; idx [E,M] int32 indices into possible_angles (optional)."""
@@ -281,6 +300,7 @@ class VecEnviron(ParamAttrs):
         self._chan += 1
         N.check(N.load().risvec_random_phase(C.byref(self._cstate), _dev_ptr(i), self.seed, self._chan,
                                              self._stream()))
+        self._ssum_sweeps = 0
 
     def data_rate(self, p_off, partner, n_groups) -> torch.Tensor:
         """Environment.py:331-372 on the cached gains: p_off [E,V] offload power in W -> rate [E,V]."""
@@ -315,11 +335,13 @@ class VecEnviron(ParamAttrs):
         ar = self._arg(arrivals, torch.int32, (E, V), "arrivals")
         flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
                  | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0)
-                 | (N.STEP_REUSE_COLSUM if (bcd and self._colsum_valid) else 0))
+                 | (self._bcd_flags(None, step=True) if bcd else 0))
         lib = N.load()
         fn = lib.risvec_step_fused_bcd if bcd else (lib.risvec_step_fused if fused else lib.risvec_step)
         N.check(fn(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng),
                    _dev_ptr(ar), self.seed, self._steps, flags, self._stream()))
+        if bcd:
+            self._bcd_done(flags, step=True)
         self._steps += 1
         t = self._t
         return (t["reward"], t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"],
@@ -341,6 +363,8 @@ class VecEnviron(ParamAttrs):
         N.check(N.load().risvec_sarl_step(C.byref(self._cstate), C.byref(sp), _dev_ptr(a), _dev_ptr(ph),
                                           _dev_ptr(ar), self.seed, self._steps, N.STEP_OBS if obs else 0,
                                           self._stream()))
+        if ph is not None:
+            self._ssum_sweeps = 0
         self._steps += 1
         t = self._t
         return (t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"], t["over_data"])
@@ -358,9 +382,8 @@ class VecEnviron(ParamAttrs):
         pt = self._arg(partner, torch.int32, (E, V), "partner")
         ng = self._arg(n_groups, torch.int32, (E,), "n_groups")
         ar = self._arg(arrivals, torch.int32, (E, V), "arrivals")
-        flags = C.c_uint32((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
-                           | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0)
-                           | (N.STEP_REUSE_COLSUM if (bcd and self._colsum_valid) else 0))
+        base_flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
+                      | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0))
         lib = N.load()
         fn = lib.risvec_step_fused_bcd if bcd else (lib.risvec_step_fused if fused else lib.risvec_step)
         cs, seed, stream = C.byref(self._cstate), C.c_uint64(self.seed), self._stream()
@@ -368,9 +391,12 @@ class VecEnviron(ParamAttrs):
         keep = (a, pt, ng, ar)           # the closure owns the marshalled tensors
 
         def launch() -> None:
+            flags = base_flags | (self._bcd_flags(None, step=True) if bcd else 0)
             rc = fn(cs, C.byref(self._p()), pa, pp, pn, par, seed, self._steps, flags, stream)
             if rc:
                 N.check(rc)
+            if bcd:
+                self._bcd_done(flags, step=True)
             self._steps += 1
 
         launch.inputs = keep
@@ -424,6 +450,7 @@ class VecEnviron(ParamAttrs):
         for k in self._STATE_KEYS:
             t[k].copy_(sd[k])
         self._colsum_valid = False
+        self._ssum_sweeps = 0
         c = sd["counters"]
         self._epoch, self._moves, self._steps, self._chan = c["epoch"], c["moves"], c["steps"], c["chan"]
 

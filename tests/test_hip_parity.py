@@ -53,6 +53,22 @@ def c128(t):
     return cpu(torch.view_as_complex(t)).astype(np.complex128)
 
 
+def snap(th, bbit):
+    """What the BCD kernel uses for a stored complex64 theta: the exact float64 candidate phasor when
+    the element is the float32 image of one (the reference keeps theta as complex128), else as stored."""
+    ang = orc.possible_angles(bbit)
+    cand = np.cos(ang) + 1j * np.sin(ang)
+    if bbit == 3:                      # the kernel's closed form for 2^b = 8
+        r = 0.70710678118654757
+        cand = np.array([1, r + 1j * r, 1j, -r + 1j * r, -1, -r - 1j * r, -1j, r - 1j * r])
+    c32 = cand.astype(np.complex64)
+    out = np.array(th, dtype=np.complex128, copy=True)
+    t32 = out.astype(np.complex64)
+    for k in range(len(cand)):
+        out[t32 == c32[k]] = cand[k]
+    return out
+
+
 def put_complex(t, z):
     t.copy_(torch.from_numpy(np.stack([z.real, z.imag], -1).astype(np.float32)))
 
@@ -248,7 +264,7 @@ def test_bcd_golden(name):
     t = env.tensors
     put_complex(t["h_r"], g["h_r"]); put_complex(t["theta"], g["theta0"])
     t["pl"].copy_(torch.from_numpy(orc.pathloss_factor(g["dist"]).astype(np.float32)))
-    h32, th32, b32 = c128(t["h_r"]), c128(t["theta"]), c128(t["b"])
+    h32, th32, b32 = c128(t["h_r"]), snap(c128(t["theta"]), bbit), c128(t["b"])
     idx = cpu(env.optimize_phase_shift(return_idx=True))
     th1 = c128(t["theta"])
     # (a) same float32 inputs through the oracle: decisions must be identical unless a
@@ -676,8 +692,8 @@ def test_colsum_cache(V, M):
     i2 = cpu(env.optimize_phase_shift(return_idx=True, reuse_colsum=False))
     assert np.array_equal(i1, i2) and np.array_equal(th1, cpu(t["theta"]))
     # and matches the oracle on the same float32 inputs
-    o_th, o_idx = orc.bcd_sweep(c128(th0), c128(t["h_r"]), c128(t["b"]), np.ones((E, V)), 3)
-    gap = orc.bcd_margin(c128(th0), c128(t["h_r"]), c128(t["b"]), 3)
+    o_th, o_idx = orc.bcd_sweep(snap(c128(th0), 3), c128(t["h_r"]), c128(t["b"]), np.ones((E, V)), 3)
+    gap = orc.bcd_margin(snap(c128(th0), 3), c128(t["h_r"]), c128(t["b"]), 3)
     safe = np.minimum.accumulate(gap, axis=1) > 1e-9
     assert safe.mean() > 0.98 and np.array_equal(i1[safe], o_idx[safe])
 
@@ -780,7 +796,7 @@ def test_edge_shapes_full_protocol(E, V, M, b):
     dist, ang, h_r = orc.geometry(cpu(t["pos"]), M)
     np.testing.assert_allclose(c128(t["h_r"]), h_r, rtol=0, atol=1.2e-7)
     env.Random_phase()
-    th0 = c128(t["theta"])
+    th0 = snap(c128(t["theta"]), b)
     idx = cpu(env.optimize_phase_shift(return_idx=True))
     o_th, o_idx = orc.bcd_sweep(th0, c128(t["h_r"]), c128(t["b"]), dist, b)
     gap = orc.bcd_margin(th0, c128(t["h_r"]), c128(t["b"]), b)
@@ -806,3 +822,34 @@ def test_edge_shapes_full_protocol(E, V, M, b):
     env2.update_channel_gains()
     out2 = env2.step(action, partner.astype(np.int32), ng.astype(np.int32), arrivals.astype(np.int32), fused=False)
     assert np.isclose(cpu(out2[2]), cpu(out[2]), rtol=1e-5, atol=1e-5).all()
+
+
+def test_bcd_cached_sum_across_sweeps():
+    """Consecutive sweeps start from the sum theta.c the previous sweep left in s_sum (no re-summing
+    pass); a direct write to theta must be announced with invalidate_colsum()."""
+    E, V, M = 200, 8, 64
+    rng = np.random.default_rng(4)
+    env = make_vec(E, V, M)
+    t = env.tensors
+    t["pos"].copy_(torch.from_numpy(np.stack([rng.uniform(0, 400, (E, V)), rng.uniform(0, 400, (E, V))], -1)))
+    env.compute_parms(); env.Random_phase()
+    h, b = c128(t["h_r"]), c128(t["b"])
+    th = snap(c128(t["theta"]), 3)
+    for sweep in range(4):
+        idx = cpu(env.optimize_phase_shift(return_idx=True))
+        assert env._ssum_sweeps == sweep + 1                     # sweeps 2.. reuse the cached sum
+        o_th, o_idx = orc.bcd_sweep(th, h, b, np.ones((E, V)), 3)
+        gap = orc.bcd_margin(th, h, b, 3)
+        safe = np.minimum.accumulate(gap, axis=1) > 1e-9
+        assert safe.mean() > 0.98 and np.array_equal(idx[safe], o_idx[safe]), sweep
+        th = snap(c128(t["theta"]), 3)
+        S = cpu(t["s_sum"]); S = S[:, 0] + 1j * S[:, 1]
+        want = np.sum(th * (h.sum(axis=1) * b[None, :]), axis=1)
+        np.testing.assert_allclose(S, want, rtol=1e-11, atol=1e-11)
+    put_complex(t["theta"], np.exp(1j * rng.uniform(0, 6.28, (E, M))))
+    env.invalidate_colsum()
+    th = snap(c128(t["theta"]), 3)
+    idx = cpu(env.optimize_phase_shift(return_idx=True))
+    o_th, o_idx = orc.bcd_sweep(th, h, b, np.ones((E, V)), 3)
+    safe = np.minimum.accumulate(orc.bcd_margin(th, h, b, 3), axis=1) > 1e-9
+    assert np.array_equal(idx[safe], o_idx[safe])
