@@ -187,41 +187,52 @@ k_mobility(Dims d, RisVecParams P, double* __restrict__ pos, int32_t* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// K2b geometry: one thread per (env, vehicle, pair of RIS elements)
+// K2b geometry: one thread per (env, vehicle, chunk of kGeoChunk RIS elements)
 // ---------------------------------------------------------------------------
+// phases_R_i[v][m] = exp(-j 2 pi/lamb d ang m) = exp(-j pi ang m) (lamb = 1, d = 0.5; ENV:253).
+// |arg| reaches ~800 rad at m = 255, so everything is float64 until the final rounding.  A thread
+// evaluates two sincospi - the chunk's first element and the per-element rotation w =
+// exp(-j pi ang) - and walks the chunk with z <- z w (16 rotations: ~2e-15 accumulated error),
+// instead of one sincospi per element.  A chunk is 128 contiguous bytes of the row.
+constexpr int kGeoChunk = 16;
+
 __global__ void __launch_bounds__(kBlock)
 k_geometry(Dims d, const double* __restrict__ pos, float* __restrict__ dist_r,
            float* __restrict__ ang_r, float* __restrict__ pl, float* __restrict__ h_r) {
-    const int npair = (d.M + 1) / 2;
+    const int nchunk = (d.M + kGeoChunk - 1) / kGeoChunk;
     const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= (long long)d.E * d.V * npair) return;
-    const long long ev = idx / npair;
-    const int q = (int)(idx % npair);
+    if (idx >= (long long)d.E * d.V * nchunk) return;
+    const long long ev = idx / nchunk;
+    const int m0 = (int)(idx % nchunk) * kGeoChunk;
     const double x = pos[ev * 2], y = pos[ev * 2 + 1];
     const double dx = x - kRisX, dy = y - kRisY, dz = kVehZ - kRisZ;
     const double dist = sqrt(dx * dx + dy * dy + dz * dz);                  // ENV:245-246
     const double ang = dx / dist;                                           // ENV:248
-    if (q == 0) {
+    if (m0 == 0) {
         dist_r[ev] = (float)dist;
         ang_r[ev] = (float)ang;
         const double d_br = sqrt((kBsX - kRisX) * (kBsX - kRisX) + (kBsY - kRisY) * (kBsY - kRisY)
                                  + (kBsZ - kRisZ) * (kBsZ - kRisZ));        // ENV:175-176
         pl[ev] = (float)((kRo * kRo) / (pow(dist, kAlpha1) * pow(d_br, kAlpha2)));   // ENV:270-272
     }
-    // phases_R_i[v][m] = exp(-j 2 pi/lamb d ang m) = exp(-j pi ang m)  (lamb=1, d=0.5; ENV:253)
-    const int m0 = 2 * q;
-    double s0, c0, s1, c1;
-    sincospi(ang * (double)m0, &s0, &c0);
+    double zs, zc, ws, wc;
+    sincospi(ang * (double)m0, &zs, &zc);          // z = exp(-j pi ang m0) = (zc, -zs)
+    sincospi(ang, &ws, &wc);                       // w = exp(-j pi ang)    = (wc, -ws)
+    double zr = zc, zi = -zs;
+    const double wr = wc, wi = -ws;
     float* out = h_r + (ev * d.M + m0) * 2;
-    if (m0 + 1 < d.M) {
-        sincospi(ang * (double)(m0 + 1), &s1, &c1);
-        if ((d.M & 1) == 0) {
-            *reinterpret_cast<float4*>(out) = make_float4((float)c0, (float)-s0, (float)c1, (float)-s1);
-        } else {
-            out[0] = (float)c0; out[1] = (float)-s0; out[2] = (float)c1; out[3] = (float)-s1;
+    const bool vec = (d.M & 1) == 0;               // even M: rows are 16-byte aligned, pairs never straddle
+#pragma unroll
+    for (int k = 0; k < kGeoChunk; k += 2) {
+        const double ar = zr, ai = zi;
+        const double br = ar * wr - ai * wi, bi = ar * wi + ai * wr;        // next element
+        zr = br * wr - bi * wi; zi = br * wi + bi * wr;                     // the one after
+        if (m0 + k + 1 < d.M) {
+            if (vec) *reinterpret_cast<float4*>(out + 2 * k) = make_float4((float)ar, (float)ai, (float)br, (float)bi);
+            else { out[2 * k] = (float)ar; out[2 * k + 1] = (float)ai; out[2 * k + 2] = (float)br; out[2 * k + 3] = (float)bi; }
+        } else if (m0 + k < d.M) {
+            out[2 * k] = (float)ar; out[2 * k + 1] = (float)ai;
         }
-    } else {
-        out[0] = (float)c0; out[1] = (float)-s0;
     }
 }
 
@@ -326,7 +337,7 @@ hipError_t launch_mobility(const RisVecState& s, const RisVecParams& p, const fl
 }
 
 hipError_t launch_geometry(const RisVecState& s, const RisVecParams&, hipStream_t st) {
-    const long long n = (long long)s.n_envs * s.n_veh * ((s.n_ris + 1) / 2);
+    const long long n = (long long)s.n_envs * s.n_veh * ((s.n_ris + kGeoChunk - 1) / kGeoChunk);
     hipLaunchKernelGGL(k_geometry, dim3(blocks_for(n)), dim3(kBlock), 0, st, dims_of(s), s.pos,
                        s.dist_r, s.ang_r, s.pl, s.h_r);
     return hipGetLastError();
