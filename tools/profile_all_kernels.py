@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Launch every kernel of the library N times at one shape so that
+`rocprofv3 --kernel-trace --stats -- python3 tools/profile_all_kernels.py` yields a per-kernel
+average duration; prints the algorithmic bytes each launch must move, for the roofline table in
+DESIGN.md.   usage: profile_all_kernels.py [E V M reps]"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ris_vec_marl_amd import VecEnviron, reference_lanes, apply_yaml_config  # noqa: E402
+
+E, V, M, reps = (int(x) for x in (sys.argv[1:5] + ["32768", "8", "64", "20"][len(sys.argv) - 1:]))
+L = reference_lanes()
+env = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3,
+                 n_envs=E, device="cuda:0", seed=0)
+apply_yaml_config(env, None)
+rng = np.random.default_rng(0)
+action = torch.from_numpy(rng.uniform(0, 1, (E, 2, V)).astype(np.float32)).cuda()
+partner = torch.full((E, V), -1, dtype=torch.int32).cuda()
+ng = torch.full((E,), V, dtype=torch.int32).cuda()
+phase = torch.from_numpy(rng.uniform(0, 6.28, (E, M)).astype(np.float32)).cuda()
+pw = action[:, 0, :].contiguous()
+for _ in range(reps):
+    env.make_new_game()
+    env.renew_positions()
+    env.compute_parms()                # k_geometry + k_colsum
+    env.Random_phase()
+    env.get_next_phase(phase)
+    env.optimize_phase_shift()         # k_bcd_sweep (column sums cached)
+    env.update_channel_gains()         # k_gain
+    env.data_rate(pw, partner, ng)
+    env.step(action, partner, ng, None, fused=False, power_w=False)
+    env.step(action, partner, ng, None, fused=True, power_w=False)
+    env.sarl_step(action, phase)
+    env.channel_model = "3gpp_umi"
+    env.update_channel_gains()
+    env.channel_model = "free"
+torch.cuda.synchronize()
+B = dict(
+    k_reset=E * V * (16 + 4 + 4 + 4), k_mobility=E * V * (16 + 4 + 4 + 16 + 4), k_geometry=E * V * (16 + 12 + 8 * M),
+    k_colsum=E * (8 * V * M + 16 * M), k_random_phase=E * 8 * M, k_set_phase=E * 12 * M,
+    k_bcd_sweep=E * (2 * 16 * M + 2 * 8 * M + 8 * M), k_gain=E * (8 * V * M + 8 * M + 8 * V),
+    k_data_rate=E * 16 * V + 4 * E, k_step=E * (60 * V + 68), k_step_fused=E * (8 * V * M + 8 * M + 64 * V + 68),
+    k_sarl_step=E * (8 * V * M + 8 * M + 48 * V + 4), k_gain_3gpp=E * V * 20)
+print(json.dumps(dict(E=E, V=V, M=M, reps=reps, algorithmic_bytes=B)))
