@@ -301,20 +301,25 @@ k_set_phase(long long n, const float* __restrict__ angle, float* __restrict__ th
 __global__ void __launch_bounds__(kBlock)
 k_random_phase(Dims d, const int32_t* __restrict__ idx, float* __restrict__ theta, uint64_t seed,
                uint32_t counter) {
+    __shared__ float2 s_cand[64];                                           // exp(j possible_angles[k]), ENV:169
+    const int nc = 1 << d.cbit;
+    if ((int)threadIdx.x < nc) {
+        double s, c;
+        sincospi(2.0 * (double)threadIdx.x / (double)nc, &s, &c);
+        s_cand[threadIdx.x] = make_float2((float)c, (float)s);
+    }
+    __syncthreads();
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= (long long)d.E * d.M) return;
     const int e = (int)(i / d.M), m = (int)(i % d.M);
-    const int nc = 1 << d.cbit;
     int k;
     if (idx) {
-        k = idx[i];
+        k = idx[i] & (nc - 1);
     } else {
         const uint4 r = philox4x32_10((uint32_t)(d.env_offset + e), (uint32_t)m, counter, kSitePhase, seed);
         k = randint_u32(r.x, 0, nc);                                        // ENV:204
     }
-    double s, c;
-    sincospi(2.0 * (double)k / (double)nc, &s, &c);                         // ENV:169, 206
-    *reinterpret_cast<float2*>(theta + 2 * i) = make_float2((float)c, (float)s);
+    *reinterpret_cast<float2*>(theta + 2 * i) = s_cand[k];                  // ENV:206
 }
 
 // ---------------------------------------------------------------------------

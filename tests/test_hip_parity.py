@@ -853,3 +853,40 @@ def test_bcd_cached_sum_across_sweeps():
     o_th, o_idx = orc.bcd_sweep(th, h, b, np.ones((E, V)), 3)
     safe = np.minimum.accumulate(orc.bcd_margin(th, h, b, 3), axis=1) > 1e-9
     assert np.array_equal(idx[safe], o_idx[safe])
+
+
+def test_long_rollout_tracks_oracle():
+    """300 fused steps with in-kernel Philox arrivals, state carried on the device, against the
+    float64 oracle stepping the same envs: the queues must not drift apart (the dynamics are
+    contracting: buffers drain), and per-step rewards agree except at QoS-threshold flips."""
+    E, V, M, T, seed = 512, 8, 64, 300, 99
+    rng = np.random.default_rng(1)
+    p = orc.OracleParams.yaml_effective()
+    p.rate = 3.0                                   # heavier load so queues build up and drain
+    env = make_vec(E, V, M, seed=seed, yaml=True)
+    env.rate = 3.0
+    env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase(); env.optimize_phase_shift()
+    t = env.tensors
+    img = np.einsum("em,evm,m->ev", c128(t["theta"]), c128(t["h_r"]), c128(t["b"]))
+    gain = cpu(t["pl"]).astype(np.float64) * np.abs(img) ** 2
+    buf = cpu(t["data_buf"]).astype(np.float64); q = np.zeros(E)
+    actions = rng.uniform(0, 1, (4, E, 2, V)).astype(np.float32)
+    a_dev = [torch.from_numpy(a).cuda() for a in actions]
+    _, partner, ng, _ = random_step_inputs(E, V, rng)
+    pt, ngt = torch.from_numpy(partner.astype(np.int32)).cuda(), torch.from_numpy(ng.astype(np.int32)).cuda()
+    bad = tot = 0
+    max_buf_err = max_q_err = 0.0
+    for s in range(T):
+        out = env.step(a_dev[s % 4], pt, ngt, None, fused=True)
+        arr = orc.philox_arrivals(np.arange(E), V, s, seed, 3.0)
+        o = orc.step(buf, q, gain, actions[s % 4].astype(np.float64), partner, ng, arr, p)
+        buf, q = o["data_buf"], o["mec_q"]
+        if s % 25 == 24 or s == T - 1:
+            r = cpu(out[0])
+            ok = np.isclose(r, o["reward"], rtol=1e-4, atol=1e-6)
+            bad += int((~ok).sum()); tot += ok.size
+            max_buf_err = max(max_buf_err, float(np.abs(cpu(out[2]) - buf).max() / max(1.0, buf.max())))
+            max_q_err = max(max_q_err, float(np.abs(cpu(t["mec_q"]) - q).max() / (p.f_edge_max * p.time_fast)))
+    assert buf.max() > 5.0                          # the workload really loads the queues
+    assert max_buf_err < 2e-5 and max_q_err < 2e-5, (max_buf_err, max_q_err)
+    assert bad <= 0.01 * tot, (bad, tot)
