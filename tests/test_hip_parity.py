@@ -890,3 +890,33 @@ def test_long_rollout_tracks_oracle():
     assert buf.max() > 5.0                          # the workload really loads the queues
     assert max_buf_err < 2e-5 and max_q_err < 2e-5, (max_buf_err, max_q_err)
     assert bad <= 0.01 * tot, (bad, tot)
+
+
+def test_determinism_and_side_stream():
+    """Same seed => bit-identical results, also when every launch goes to a non-default stream."""
+    E, V, M = 1000, 8, 64
+    rng = np.random.default_rng(2)
+    action, partner, ng, _ = random_step_inputs(E, V, rng)
+
+    def run(stream):
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            env = make_vec(E, V, M, seed=123, yaml=True)
+            env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase()
+            env.optimize_phase_shift(); env.optimize_phase_shift()
+            a = torch.from_numpy(action.astype(np.float32)).cuda()
+            for _ in range(5):
+                env.step(a, partner.astype(np.int32), ng.astype(np.int32), None, fused=True)
+            env.update_channel_gains()
+            env.step(a, partner.astype(np.int32), ng.astype(np.int32), None, fused=False)
+            if stream is not None:
+                stream.synchronize()
+            torch.cuda.synchronize()
+            t = env.tensors
+            return [cpu(t[k]).copy() for k in ("pos", "theta", "gain", "data_buf", "mec_q", "reward", "metrics", "obs", "s_sum")]
+
+    a = run(None)
+    b = run(None)
+    c = run(torch.cuda.Stream())
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
