@@ -269,7 +269,12 @@ hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, c
     if (V == 8 && M == 40) return launch_pipe<8, 40, 2>(s, p, a, st);
     if (V == 4 && M == 16) return launch_pipe<4, 16, 4>(s, p, a, st);
     if (V == 16 && M == 64) return launch_pipe<16, 64, 2>(s, p, a, st);
-    if (V == 16 && M == 256) return launch_pipe<16, 256, 2>(s, p, a, st);
+    if (V == 16 && M == 256) {
+        static const int depth = [] { const char* e = std::getenv("RISVEC_PIPE_DEPTH"); return e ? std::atoi(e) : 2; }();
+        if (depth == 1) return launch_pipe<16, 256, 1>(s, p, a, st);
+        if (depth == 4) return launch_pipe<16, 256, 4>(s, p, a, st);
+        return launch_pipe<16, 256, 2>(s, p, a, st);
+    }
     return hipErrorNotSupported;
 }
 
