@@ -148,7 +148,8 @@ typedef struct RisVecState {
     float *metrics;         /* [E,16]  see RISVEC_METRIC_* (slots 14,15 reserved = 0) */
     float *power_w;         /* [E,2,V] last_power_W (may be NULL unless flag set)     */
     /* BCD cache: c[e,m] = (sum_v h_r[e,v,m]) * b[m] in float64 (pure geometry, like `pl`) */
-    double *c_col;          /* [E,M]   c128; written by risvec_geometry / risvec_colsum */
+    double *c_col;          /* c128, ceil(E/64)*64*M elements, LANE-MAJOR: (e,m) at ((e/64)*M+m)*64+e%64;
+                               written by risvec_geometry / risvec_colsum, read only by risvec_bcd   */
     double *s_sum;          /* [E]     c128; S = sum_m theta_m c_m left by the last BCD sweep (may be NULL) */
     /* SARL variant only (Simulation-SARL/Environment.py:337-340); the MARL step never writes it */
     float *over_data;       /* [E,V]   (may be NULL for MARL-only use)                 */

@@ -23,10 +23,11 @@
 //                 flight per lane.  c is pure geometry (it changes only when h_r does), so it is
 //                 cached in HBM like the path-loss factor: risvec_geometry rebuilds it, and a
 //                 BCD call may reuse it.
-//   k_bcd_sweep   ONE LANE PER ENV walks the chain, streaming its env's c row and theta row
-//                 through registers, a block of 16 elements (two 128-byte lines of c) ahead of
-//                 the chain.  No LDS staging, so nothing but the chain's own latency bounds
-//                 the envs in flight (an earlier LDS-staged form was capped at 38 envs per CU).
+//   k_bcd_sweep   ONE LANE PER ENV walks the chain; c streams from a lane-major cache, theta tiles
+//                 are transposed through LDS (see the kernel).  An earlier form that staged c for
+//                 whole envs in LDS was capped by LDS capacity at 38 envs per CU in flight.
+#include <cstdlib>
+
 #include "risvec_step.hpp"
 
 namespace risvec {
@@ -144,39 +145,44 @@ k_colsum(Dims d, const float* __restrict__ h_r, const float* __restrict__ b, dou
     s0r += xchg<1>(s0r); s0i += xchg<1>(s0i);
     if constexpr (VEC == 2) { s1r += xchg<1>(s1r); s1i += xchg<1>(s1i); }
     if (!in) return;
-    double2* __restrict__ out = reinterpret_cast<double2*>(c_col) + e * M;
+    // c_col is private to the BCD kernels and stored LANE-MAJOR: element (e, m) lives at
+    // ((e / 64) * M + m) * 64 + e % 64, so the sweep's 64 lanes (64 consecutive envs) read one
+    // element each from 1 KiB of contiguous memory.  The price is paid here, once per geometry
+    // refresh: these 16-byte stores are 1 KiB apart.
+    double2* __restrict__ out = reinterpret_cast<double2*>(c_col) + ((e >> 6) * M) * 64 + (e & 63);
     if constexpr (VEC == 2) {
         const float4 bb = reinterpret_cast<const float4*>(b)[p];
         const double sr = vh ? s1r : s0r, si = vh ? s1i : s0i;
         const double br = vh ? bb.z : bb.x, bi = vh ? bb.w : bb.y;
-        out[2 * p + vh] = make_double2(sr * br - si * bi, sr * bi + si * br);
+        out[(long long)(2 * p + vh) * 64] = make_double2(sr * br - si * bi, sr * bi + si * br);
     } else if (vh == 0) {
         const float2 bb = reinterpret_cast<const float2*>(b)[p];
-        out[p] = make_double2(s0r * bb.x - s0i * bb.y, s0r * bb.y + s0i * bb.x);
+        out[(long long)p * 64] = make_double2(s0r * bb.x - s0i * bb.y, s0r * bb.y + s0i * bb.x);
     }
 }
 
 // ---------------------------------------------------------------------------
 // k_bcd_sweep
 // ---------------------------------------------------------------------------
-// A wave owns 64 envs, one lane each.  The rows a lane walks (c[e,:] and theta[e,:]) are 4 KiB
-// and 2 KiB apart between lanes, so a per-lane load would touch 64 cache lines per instruction;
-// measured, that - not the chain - bounded the kernel (fewer envs per wave made it slower).  So
-// tiles move COOPERATIVELY: 8 lanes read one env's 128-byte line, an instruction covers 8 envs
-// with full lines, the tile is transposed through LDS, and each lane then reads its own row from
-// LDS.  New theta goes back the same way.  The next tile's global loads are issued before the
-// current tile's 8 chain steps, so they land underneath them.
-constexpr int kSweepBlk = 8;                                // elements per tile (128 B of c, 64 B of theta per env);
-                                                            // 16 would need >256 VGPRs (measured: spills, 3x slower)
-constexpr int kCRow = kSweepBlk + 1;                        // LDS row strides (in elements): +1 keeps the
-constexpr int kTRow = kSweepBlk + 2;                        // 16-lane read groups on distinct banks
+// A wave owns 64 consecutive envs, one lane each.
+//   c      is read straight from the lane-major c_col: one element per lane, 1 KiB contiguous
+//          per instruction, 8 elements ahead of the chain.
+//   theta  keeps its public row-major [E,M] layout (the gain kernels read it along m), where the
+//          rows of neighbouring lanes are 8M bytes apart.  A per-lane access would touch 64
+//          cache lines per instruction (measured: that, not the chain, bounded the kernel), so
+//          theta tiles move COOPERATIVELY - 4 lanes read one env's 64 bytes, 16 envs per
+//          instruction - and are transposed through LDS; the new theta goes back the same way.
+// Measured on the way here (C5 shape, 32 768 envs): neither more waves per SIMD (8/16/32 envs per
+// wave) nor longer tiles changed the time, i.e. the kernel is bound by how efficiently HBM
+// serves its accesses, which is why c moved to a layout that streams.
+constexpr int kSweepBlk = 8;                                // elements per tile
+constexpr int kTRow = kSweepBlk + 2;                        // LDS row stride of the theta tile (elements)
 
 template <int NC>
 __global__ void __launch_bounds__(kWave)
 k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
             int32_t* __restrict__ idx_out, double* __restrict__ s_sum, int reuse_s) {
     __shared__ double2 s_cand[NC];
-    __shared__ double2 s_c[kWave * kCRow];                  // 9 216 B
     __shared__ float2 s_t[kWave * kTRow];                   // 5 120 B
     const int M = d.M;
     const int lane = threadIdx.x;
@@ -190,24 +196,17 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
     const long long e_last = d.E - 1;
     const bool live = e0 + lane < d.E;
     const long long e = live ? e0 + lane : e_last;
-    const double2* __restrict__ cg = reinterpret_cast<const double2*>(c_col);
+    // this wave's slab of c_col: [M][64] double2, lane-major (padded to whole slabs by the host)
+    const double2* __restrict__ cg = reinterpret_cast<const double2*>(c_col) + (long long)blockIdx.x * M * kWave + lane;
     float2* __restrict__ tg = reinterpret_cast<float2*>(theta);
     const int n_blk = (M + kSweepBlk - 1) / kSweepBlk;
-    // cooperative roles: for c, 8 lanes x 16 B cover one env's 128-byte line (8 envs per
-    // instruction); for theta, 4 lanes x 16 B cover one env's 64 bytes (16 envs per instruction)
-    const int sub = lane >> 3, q = lane & 7;
-    const int sub4 = lane >> 2, q4 = lane & 3;
+    const int sub4 = lane >> 2, q4 = lane & 3;              // theta tile roles: env sub-index, 16-byte piece
 
-    // cooperative tile fetch into registers; clamped indices keep every address valid
-    double2 pc[8];
+    double2 pc[kSweepBlk];
     float4 pt[4];
-    auto fetch = [&](int kb) {
+    auto fetch = [&](int kb) {                              // clamped indices keep every address valid
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const long long ee = min(e0 + i * 8 + sub, e_last);
-            const int m = min(kb * kSweepBlk + q, M - 1);
-            pc[i] = cg[ee * M + m];
-        }
+        for (int j = 0; j < kSweepBlk; ++j) pc[j] = cg[(long long)min(kb * kSweepBlk + j, M - 1) * kWave];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long long ee = min(e0 + i * 16 + sub4, e_last);
@@ -216,10 +215,9 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
             pt[i] = make_float4(a.x, a.y, b2.x, b2.y);
         }
     };
-    // registers -> LDS tile (transposition), then each lane takes its own row
+    // c: registers as they are; theta: registers -> LDS tile -> each lane takes its own row.
+    // Elements past M become c = theta = 0, for which a chain step leaves S unchanged.
     auto stage = [&](int kb, double2 (&cc)[kSweepBlk], float2 (&tc)[kSweepBlk]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s_c[(i * 8 + sub) * kCRow + q] = pc[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             s_t[(i * 16 + sub4) * kTRow + 2 * q4] = make_float2(pt[i].x, pt[i].y);
@@ -228,10 +226,9 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < kSweepBlk; ++j) {
-            const bool ok = kb * kSweepBlk + j < M;         // past M: c = theta = 0, a no-op for the chain
-            const double2 cv = s_c[lane * kCRow + j];
+            const bool ok = kb * kSweepBlk + j < M;
             const float2 tv = s_t[lane * kTRow + j];
-            cc[j] = make_double2(ok ? cv.x : 0.0, ok ? cv.y : 0.0);
+            cc[j] = make_double2(ok ? pc[j].x : 0.0, ok ? pc[j].y : 0.0);
             tc[j] = make_float2(ok ? tv.x : 0.f, ok ? tv.y : 0.f);
         }
         __builtin_amdgcn_wave_barrier();
@@ -266,11 +263,10 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
         Sr += Tr; Si += Ti;
     }
 
-    // ---- pass 2: the chain.  Elements past M are fed as c = theta = 0, for which a step leaves S
-    // unchanged, so the chain needs no masking.  The "no candidate scores above 0" case (new S
-    // exactly 0; ENV:211, 220) is kept OFF the dependent chain: a tile first runs without it
-    // while OR-ing a flag, and is re-run exactly from its saved start state in the (practically
-    // never taken) case that some lane raised the flag.
+    // ---- pass 2: the chain.  The "no candidate scores above 0" case (new S exactly 0; ENV:211,
+    // 220) is kept OFF the dependent chain: a tile first runs without it while OR-ing a flag, and
+    // is re-run exactly from its saved start state in the (practically never taken) case that
+    // some lane raised the flag.
     fetch(0);
     for (int kb = 0; kb < n_blk; ++kb) {
         stage(kb, cc, tc);

@@ -131,7 +131,8 @@ class VecEnviron(ParamAttrs):
         t["obs"] = z(E, V, 5)
         t["metrics"] = z(E, N.METRICS)
         t["power_w"] = z(E, 2, V)
-        t["c_col"] = z(E, M, 2, dt=torch.float64)      # BCD column sums (sum_v h_r) * b, f64
+        # BCD column sums (sum_v h_r) * b in f64, lane-major slabs of 64 envs: [ceil(E/64), M, 64, 2]
+        t["c_col"] = z((E + 63) // 64, M, 64, 2, dt=torch.float64)
         t["s_sum"] = z(E, 2, dt=torch.float64)         # sum_m theta_m c_m left by the last sweep
         s = N.RisVecState()
         s.abi_version = N.ABI_VERSION
@@ -235,6 +236,11 @@ class VecEnviron(ParamAttrs):
         N.check(N.load().risvec_colsum(C.byref(self._cstate), self._stream()))
         self._colsum_valid = True
         self._ssum_sweeps = 0
+
+    def colsum_rows(self) -> torch.Tensor:
+        """The BCD cache as [E, M] complex128 (a copy; the device layout is lane-major slabs)."""
+        c = torch.view_as_complex(self.tensors["c_col"])            # [S, M, 64]
+        return c.permute(0, 2, 1).reshape(-1, self.M)[: self.n_envs].clone()
 
     def invalidate_colsum(self) -> None:
         """Tell the env that h_r or theta was modified behind its back (a direct write to
