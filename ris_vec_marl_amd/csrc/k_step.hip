@@ -124,6 +124,10 @@ static hipError_t launch_gain_g(const RisVecState& s, hipStream_t st) {
 }
 
 hipError_t launch_gain(const RisVecState& s, const RisVecParams&, hipStream_t st) {
+    {
+        const hipError_t err = launch_gain_pipe(s, st);     // compile-time shapes: pipelined form
+        if (err != hipErrorNotSupported) return err;
+    }
     const int vec = (s.n_ris & 1) ? 1 : 2;
     switch (pick_group(s.n_ris, vec, kWave)) {
         case 8: return launch_gain_g<8>(s, st);

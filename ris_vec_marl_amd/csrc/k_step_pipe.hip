@@ -16,7 +16,7 @@
 // ENV:547-731 (see risvec_step.hpp).
 #include <cstdlib>
 
-#include "risvec_step.hpp"
+#include "risvec_sarl.hpp"
 
 namespace risvec {
 
@@ -70,9 +70,100 @@ __device__ __forceinline__ void treduce(float (&val)[8], int gl) {
     }
 }
 
-template <int V, int M, int D>
+// ---------------------------------------------------------------------------
+// What runs on the reduced cascade sums: the pipeline is the same for the MARL step, the SARL
+// step and the gain-only kernel; a Core supplies its parameter / argument types, the per-lane
+// inputs it wants prefetched one group ahead, and the per-lane work.
+// ---------------------------------------------------------------------------
+struct MarlCore {
+    using Params = RisVecParams;
+    using Args = StepArgs;
+    using In = StepIn;
+    static __device__ __forceinline__ In load(const Dims& d, const Args& A, int e, int v, bool active) {
+        return load_step_in(d, A, e, v, active);
+    }
+    static __device__ __forceinline__ void hold(const In& in) {
+        asm volatile("" ::"v"(in.a0), "v"(in.a1), "v"(in.B), "v"(in.Q0), "v"(in.pl), "v"(in.part), "v"(in.G));
+    }
+    template <int VP>
+    static __device__ __forceinline__ void run(const Dims& d, const Params& P, const Args& A, int e, int v,
+                                               bool active, float2 img, const In& in) {
+        float g = 0.f;
+        if (active) {
+            const long long idx = (long long)e * d.V + v;
+            g = gain_from_img(img, in.pl, A.h_d, idx);
+            A.gain[idx] = g;
+        }
+        step_core<VP>(d, P, A, e, v, active, g, in);
+    }
+};
+
+struct SarlIn {
+    float p0, p1, B, pl;
+};
+
+struct SarlCore {
+    using Params = RisVecSarlParams;
+    using Args = SarlArgs;
+    using In = SarlIn;
+    static __device__ __forceinline__ In load(const Dims& d, const Args& A, int e, int v, bool active) {
+        In in{0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            const long long idx = (long long)e * d.V + v;
+            in.p0 = A.action_power[(long long)e * 2 * d.V + v];
+            in.p1 = A.action_power[(long long)e * 2 * d.V + d.V + v];
+            in.B = A.data_buf[idx];
+            in.pl = A.pl[idx];
+        }
+        return in;
+    }
+    static __device__ __forceinline__ void hold(const In& in) {
+        asm volatile("" ::"v"(in.p0), "v"(in.p1), "v"(in.B), "v"(in.pl));
+    }
+    template <int VP>
+    static __device__ __forceinline__ void run(const Dims& d, const Params& P, const Args& A, int e, int v,
+                                               bool active, float2 img, const In& in) {
+        float g = 0.f;
+        if (active) {
+            const long long idx = (long long)e * d.V + v;
+            g = gain_from_img(img, in.pl, nullptr, idx);
+            A.gain[idx] = g;
+        }
+        sarl_core<VP>(d, P, A, e, v, active, g, in.p0, in.p1, in.B);
+    }
+};
+
+struct GainArgs {
+    const float* pl;
+    const float* h_r;
+    const float* theta;
+    const float* b;
+    const float* h_d;
+    float* gain;
+};
+
+struct GainCore {
+    using Params = int;
+    using Args = GainArgs;
+    struct In { float pl; };
+    static __device__ __forceinline__ In load(const Dims& d, const Args& A, int e, int v, bool active) {
+        return In{active ? A.pl[(long long)e * d.V + v] : 0.f};
+    }
+    static __device__ __forceinline__ void hold(const In& in) { asm volatile("" ::"v"(in.pl)); }
+    template <int VP>
+    static __device__ __forceinline__ void run(const Dims& d, const Params&, const Args& A, int e, int v,
+                                               bool active, float2 img, const In& in) {
+        if (active) {
+            const long long idx = (long long)e * d.V + v;
+            A.gain[idx] = gain_from_img(img, in.pl, A.h_d, idx);
+        }
+    }
+};
+
+template <int V, int M, int D, class Core>
 __global__ void __launch_bounds__(kBlock)
-k_step_fused_pipe(Dims d, RisVecParams P, StepArgs A, int n_groups_total) {
+k_step_fused_pipe(Dims d, typename Core::Params P, typename Core::Args A, int n_groups_total) {
+    using In = typename Core::In;
     using S = PipeShape<V, M>;
     constexpr int VP = S::VP, EPW = S::EPW, NP = S::NP, G = S::G, NIT = S::NIT, VPP = S::VPP;
     constexpr int PC = S::PC, CHUNKS = S::CHUNKS, UPG = S::UPG, K = S::K;
@@ -133,20 +224,20 @@ k_step_fused_pipe(Dims d, RisVecParams P, StepArgs A, int n_groups_total) {
     const int v_mine = lane % VP;
 
     // One group: consume its UPG units (refilling the ring D units ahead, across the group
-    // boundary), prefetch the NEXT group's step() inputs into `in_nx`, then run step() with
+    // boundary), prefetch the NEXT group's per-lane inputs into `in_nx`, then run the core with
     // `in`.  Called alternately with (inA, inB) / (inB, inA) so no register copy - and hence
     // no wait on the prefetch - is needed at the loop boundary.
-    auto do_group = [&](int g_cur, const StepIn& in, StepIn& in_nx) {
+    auto do_group = [&](int g_cur, const In& in, In& in_nx) {
         // The prefetch is unconditional (straight-line code keeps the compiler's vmcnt
         // bookkeeping exact): a wave on its last group "prefetches" group 0 instead, which
         // every such wave shares, so those requests are served by L2 and cost no HBM traffic.
         const int nxt = (g_cur + nw < n_groups_total) ? g_cur + nw : 0;
         const int e_mine = g_cur * EPW + lane / VP;
         const bool active = e_mine < d.E;
-        // Take the wait for this group's step() inputs HERE (they were requested a whole
-        // step() ago), not at their first use inside step(), where the compiler could only
+        // Take the wait for this group's per-lane inputs HERE (they were requested a whole
+        // group ago), not at their first use inside the core, where the compiler could only
         // express it as vmcnt(0) and would drain the next group's prefetch with it.
-        asm volatile("" ::"v"(in.a0), "v"(in.a1), "v"(in.B), "v"(in.Q0), "v"(in.pl), "v"(in.part), "v"(in.G));
+        Core::hold(in);
 
         float2 w0[NIT], w1[NIT];
 #pragma unroll
@@ -182,24 +273,18 @@ k_step_fused_pipe(Dims d, RisVecParams P, StepArgs A, int n_groups_total) {
             if (ui + D < UPG) load_unit(u, g_cur, ui + D);
             else load_unit(u, nxt, ui + D - UPG);
         }
-        // step() inputs of the next group: in flight during this group's step()
-        in_nx = load_step_in(d, A, nxt * EPW + lane / VP, v_mine, nxt * EPW + lane / VP < d.E);
+        // per-lane inputs of the next group: in flight during this group's core
+        in_nx = Core::load(d, A, nxt * EPW + lane / VP, v_mine, nxt * EPW + lane / VP < d.E);
 
         // the wave's own LDS writes -> its own reads (LDS is in-order per wave; no other wave
         // touches this slice); the barrier only pins the compiler's ordering
         __builtin_amdgcn_wave_barrier();
-        float g = 0.f;
-        if (active) {
-            const long long idx = (long long)e_mine * V + v_mine;
-            const float2 img = *reinterpret_cast<const float2*>(&s_img[wave][lane * 2]);
-            g = gain_from_img(img, in.pl, A.h_d, idx);
-            A.gain[idx] = g;
-        }
-        step_core<VP>(d, P, A, e_mine, v_mine, active, g, in);
+        const float2 img = *reinterpret_cast<const float2*>(&s_img[wave][lane * 2]);
+        Core::template run<VP>(d, P, A, e_mine, v_mine, active, img, in);
         __builtin_amdgcn_wave_barrier();
     };
 
-    StepIn inA = load_step_in(d, A, grp * EPW + lane / VP, v_mine, grp * EPW + lane / VP < d.E), inB;
+    In inA = Core::load(d, A, grp * EPW + lane / VP, v_mine, grp * EPW + lane / VP < d.E), inB;
     while (true) {
         do_group(grp, inA, inB);
         grp += nw;
@@ -238,8 +323,9 @@ static int num_cus() {
     return n;
 }
 
-template <int V, int M, int D>
-static hipError_t launch_pipe(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
+template <int V, int M, int D, class Core>
+static hipError_t launch_pipe(const RisVecState& s, const typename Core::Params& p, const typename Core::Args& a,
+                              hipStream_t st) {
     using S = PipeShape<V, M>;
     const int n_groups = (s.n_envs + S::EPW - 1) / S::EPW;
     const int wpb = kBlock / kWave;
@@ -249,33 +335,48 @@ static hipError_t launch_pipe(const RisVecState& s, const RisVecParams& p, const
     const long long per_wave = (n_groups + want_waves - 1) / want_waves;
     want_waves = (n_groups + per_wave - 1) / per_wave;
     const unsigned grid = (unsigned)((want_waves + wpb - 1) / wpb);
-    hipLaunchKernelGGL((k_step_fused_pipe<V, M, D>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_groups);
+    hipLaunchKernelGGL((k_step_fused_pipe<V, M, D, Core>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_groups);
     return hipGetLastError();
+}
+
+static bool pipe_disabled() {
+    static const bool off = std::getenv("RISVEC_NO_PIPE") != nullptr;    // A/B switch for experiments
+    return off;
+}
+
+// compile-time shapes shared by the three cores
+template <class Core>
+static hipError_t dispatch_pipe(const RisVecState& s, const typename Core::Params& p, const typename Core::Args& a,
+                                hipStream_t st) {
+    if (pipe_disabled()) return hipErrorNotSupported;
+    const int V = s.n_veh, M = s.n_ris;
+    if (V == 8 && M == 64) return launch_pipe<8, 64, 2, Core>(s, p, a, st);
+    if (V == 8 && M == 36) return launch_pipe<8, 36, 2, Core>(s, p, a, st);
+    if (V == 8 && M == 40) return launch_pipe<8, 40, 2, Core>(s, p, a, st);
+    if (V == 4 && M == 16) return launch_pipe<4, 16, 4, Core>(s, p, a, st);
+    if (V == 16 && M == 64) return launch_pipe<16, 64, 2, Core>(s, p, a, st);
+    if (V == 16 && M == 256) return launch_pipe<16, 256, 2, Core>(s, p, a, st);
+    return hipErrorNotSupported;
 }
 
 hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, const StepArgs& a,
                                   hipStream_t st) {
-    static const bool off = std::getenv("RISVEC_NO_PIPE") != nullptr;    // A/B switch for experiments
-    if (off) return hipErrorNotSupported;
-    const int V = s.n_veh, M = s.n_ris;
-    if (V == 8 && M == 64) {
+    if (!pipe_disabled() && s.n_veh == 8 && s.n_ris == 64) {             // ring-depth experiment knob
         static const int depth = [] { const char* e = std::getenv("RISVEC_PIPE_DEPTH"); return e ? std::atoi(e) : 2; }();
-        if (depth == 1) return launch_pipe<8, 64, 1>(s, p, a, st);
-        if (depth == 4) return launch_pipe<8, 64, 4>(s, p, a, st);
-        if (depth == 8) return launch_pipe<8, 64, 8>(s, p, a, st);
-        return launch_pipe<8, 64, 2>(s, p, a, st);
+        if (depth == 1) return launch_pipe<8, 64, 1, MarlCore>(s, p, a, st);
+        if (depth == 4) return launch_pipe<8, 64, 4, MarlCore>(s, p, a, st);
+        if (depth == 8) return launch_pipe<8, 64, 8, MarlCore>(s, p, a, st);
     }
-    if (V == 8 && M == 36) return launch_pipe<8, 36, 2>(s, p, a, st);
-    if (V == 8 && M == 40) return launch_pipe<8, 40, 2>(s, p, a, st);
-    if (V == 4 && M == 16) return launch_pipe<4, 16, 4>(s, p, a, st);
-    if (V == 16 && M == 64) return launch_pipe<16, 64, 2>(s, p, a, st);
-    if (V == 16 && M == 256) {
-        static const int depth = [] { const char* e = std::getenv("RISVEC_PIPE_DEPTH"); return e ? std::atoi(e) : 2; }();
-        if (depth == 1) return launch_pipe<16, 256, 1>(s, p, a, st);
-        if (depth == 4) return launch_pipe<16, 256, 4>(s, p, a, st);
-        return launch_pipe<16, 256, 2>(s, p, a, st);
-    }
-    return hipErrorNotSupported;
+    return dispatch_pipe<MarlCore>(s, p, a, st);
+}
+
+hipError_t launch_sarl_pipe(const RisVecState& s, const RisVecSarlParams& p, const SarlArgs& a, hipStream_t st) {
+    return dispatch_pipe<SarlCore>(s, p, a, st);
+}
+
+hipError_t launch_gain_pipe(const RisVecState& s, hipStream_t st) {
+    const GainArgs a{s.pl, s.h_r, s.theta, s.b, s.h_d, s.gain};
+    return dispatch_pipe<GainCore>(s, 0, a, st);
 }
 
 }  // namespace risvec

@@ -380,5 +380,6 @@ inline StepArgs make_step_args(const RisVecState& s, const float* action, const 
 // hipErrorNotSupported when the shape has no specialisation.
 hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, const StepArgs& a,
                                   hipStream_t st);
+hipError_t launch_gain_pipe(const RisVecState& s, hipStream_t st);
 
 }  // namespace risvec
