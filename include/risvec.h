@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 4
+#define RISVEC_ABI_VERSION 5
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -281,6 +281,95 @@ int risvec_step_fused_bcd(const RisVecState *s, const RisVecParams *p, const flo
                           const int32_t *partner, const int32_t *n_groups,
                           const int32_t *arrivals, uint64_t seed, uint32_t counter,
                           uint32_t flags, risvec_stream_t stream);
+
+/* ===========================================================================================
+ * NOMA grouping stage: the pairing the reference driver computes right before
+ * every env.step() -- marl_train_bcd.py (TRAIN): feasibility mask TRAIN:128-156 + 842-855, score
+ * matrix TRAIN:164-194, quantile-gated max-weight matching TRAIN:326-398, greedy completion
+ * TRAIN:276-324, mask relaxation TRAIN:260-275, pair QoS check TRAIN:858-880, and the per-step
+ * control logic with the freeze-in-episode safeties TRAIN:1401-1562, 1618-1623 -- for all E envs,
+ * one wavefront per env, every comparison in float64 in the reference's association order.
+ * n_veh <= 16.  Its outputs (partner / n_groups) are exactly what risvec_step* consume.
+ * =========================================================================================== */
+#define RISVEC_NOMA_MAX_VEH 16
+
+typedef struct RisVecNomaParams {
+    int32_t min_pair_target;        /* TRAIN:489   max(1, n_veh / 4); config.yaml 3        */
+    int32_t mwm_backoff_rounds;     /* TRAIN:440 / 659                                      */
+    int32_t mwm_allow_singles;      /* TRAIN:436                                            */
+    int32_t qos_enable;             /* TRAIN:750   soft QoS penalty in the score            */
+    int32_t relax_topk_step;        /* TRAIN:728                                            */
+    int32_t freeze_group_in_episode;/* TRAIN:738                                            */
+    int32_t freeze_recalc_every;    /* TRAIN:739   0 = frozen for the whole episode         */
+    int32_t mask_enable;            /* TRAIN:498   0: pairing always sees the full mask     */
+    double mwm_accept_quantile;     /* TRAIN:439                                            */
+    double mwm_accept_q_step;       /* TRAIN:441                                            */
+    double completion_min_quantile; /* TRAIN:282, 300                                       */
+    double score_w_delta_db;        /* TRAIN:716                                            */
+    double abs_gain_min_db;         /* TRAIN:723   (-inf = off)                             */
+    double qos_soft_penalty;        /* TRAIN:172, 1450                                      */
+    double qos_R_min;               /* TRAIN:751   bit/s/Hz                                 */
+    double noise_power;             /* env.noise_power (ENV:72-76)                          */
+    double P_max;                   /* env.P_max (ENV:125)                                  */
+    double relax_tau_factor;        /* TRAIN:729                                            */
+    double tau_back_floor_db;       /* TRAIN:1499                                           */
+    double freeze_reward_drop_ratio;/* TRAIN:741                                            */
+    double freeze_unstick_prob;     /* TRAIN:740                                            */
+    float score_w_history;          /* TRAIN:717   (float32 product with the float32 history) */
+    float pair_hist_decay;          /* TRAIN:719   (float32 in-place decay)                 */
+} RisVecNomaParams;
+
+enum RisVecNomaFlag {               /* bits of RisVecNomaState.flags[e]                     */
+    RISVEC_NOMA_HAS_LAST = 1,       /* last_env_global is set (TRAIN:1298, 1618)            */
+    RISVEC_NOMA_UNSTICK_USED = 2,   /* unstick_used_flag (TRAIN:1300, 1536)                 */
+    RISVEC_NOMA_HAS_GROUPS = 4      /* episode_groups is set (TRAIN:1297, 1552)             */
+};
+
+/* Episode-scoped state of TRAIN:1282-1300, device pointers, N = n_veh. */
+typedef struct RisVecNomaState {
+    int32_t n_envs, n_veh;
+    int64_t env_offset;             /* global id of local env 0 (RNG key)                   */
+    float *hist;                    /* [E,N,N] pair_affinity_hist                           */
+    int32_t *streak;                /* [E,N]   unpaired_streak                              */
+    int32_t *partner;               /* [E,N]   episode_groups, partner encoding of risvec_step */
+    int32_t *n_groups;              /* [E]     len(episode_groups)                          */
+    double *last_global;            /* [E]     last_env_global                              */
+    double *best_global;            /* [E]     ep_env_best                                  */
+    uint8_t *flags;                 /* [E]     RisVecNomaFlag bits                          */
+    uint8_t *mask;                  /* [E,N,N] last_mask_mat (0/1)                          */
+    double *tau;                    /* [E]     last_tau_now                                 */
+    double *scratch;                /* matching table spill for > 12 matchable users; may be NULL when n_veh <= 12 */
+    uint64_t scratch_bytes;         /* >= 8 << n_veh bytes per concurrently resident env (library uses as many as fit, <= 1024) */
+} RisVecNomaState;
+
+void risvec_noma_default_params(RisVecNomaParams *p, int32_t n_veh);   /* driver Config defaults */
+
+/* Start of an episode (TRAIN:1282-1300): zero hist / streak / flags. */
+int risvec_noma_begin_episode(const RisVecNomaState *ns, risvec_stream_t stream);
+
+/* Channel-refresh step (TRAIN:1319-1343): tau = quantile q_now of |g_strong - g_weak| in dB
+ * (TRAIN:842-855) -> ns->tau; with K_now >= 1 also the N x N mask (TRAIN:134-156) -> ns->mask.
+ * gain [E,N] float32 linear; gdb15 [E,N] float64 = 10 log10(max(g, 1e-15)) or NULL (computed on
+ * the device; pass it to reproduce a host's log10 bit for bit -- see DESIGN.md, f2). */
+int risvec_noma_mask(const RisVecNomaState *ns, const float *gain, const double *gdb15, double q_now,
+                     int32_t K_now, risvec_stream_t stream);
+
+/* One pass of TRAIN:1401-1562 for every env.
+ *   gain [E,N] f32; gdb12 [E,N] f64 = 10 log10(max(g, 1e-12)) or NULL; p_off01 [E,N] f32 = the
+ *   offload power in [0,1] used by the QoS check (TRAIN:1391-1396; may be NULL when qos is off);
+ *   use_mask: this step's mask_mat is ns->mask (a refresh step) / 0 = None (TRAIN:1421-1424);
+ *   q_back, K_back, tau_back [E]: last_q_now / last_K_now / last_tau_now (TRAIN:1486-1491);
+ *   prev_global (stride in floats) or NULL: global reward of the PREVIOUS step -- the
+ *   ep_env_best / last_env_global bookkeeping of TRAIN:1618-1623 is applied first;
+ *   u_unstick [E] f32 or NULL (Philox) : the draw of TRAIN:1539;
+ *   partner_out [E,N], n_groups_out [E]: this step's noma_groups for risvec_step*;
+ *   info_out [E,4] or NULL: {recomputed, back-off rounds, pairs, matchable users of the last matching}. */
+int risvec_noma_group(const RisVecNomaState *ns, const RisVecNomaParams *np, const float *gain,
+                      const double *gdb12, const float *p_off01, int32_t use_mask, double q_back,
+                      int32_t K_back, const double *tau_back, const float *prev_global,
+                      int32_t prev_global_stride, int32_t i_step, const float *u_unstick, uint64_t seed,
+                      uint32_t counter, int32_t *partner_out, int32_t *n_groups_out, int32_t *info_out,
+                      risvec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,9 @@ from .params import EnvParams, apply_yaml_config, load_yaml, reference_lanes, po
 from .vec_env import VecEnviron
 from .compat import Environ, Vehicle, encode_noma_groups
 from .sarl import SarlEnviron, SarlParams, sarl_action_map, sarl_observe
+from .noma import NomaConfig, NomaGrouper, anneal_topk
 from . import dist
 
 __all__ = ["EnvParams", "apply_yaml_config", "load_yaml", "reference_lanes", "poisson_cdf_table",
            "VecEnviron", "Environ", "Vehicle", "encode_noma_groups", "SarlEnviron", "SarlParams", "sarl_action_map",
-           "sarl_observe", "dist"]
+           "sarl_observe", "NomaConfig", "NomaGrouper", "anneal_topk", "dist"]

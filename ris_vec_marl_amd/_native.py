@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -78,6 +78,32 @@ class RisVecSarlParams(C.Structure):
     ]
 
 
+class RisVecNomaParams(C.Structure):
+    _fields_ = [
+        ("min_pair_target", C.c_int32), ("mwm_backoff_rounds", C.c_int32), ("mwm_allow_singles", C.c_int32),
+        ("qos_enable", C.c_int32), ("relax_topk_step", C.c_int32), ("freeze_group_in_episode", C.c_int32),
+        ("freeze_recalc_every", C.c_int32), ("mask_enable", C.c_int32),
+        ("mwm_accept_quantile", C.c_double), ("mwm_accept_q_step", C.c_double),
+        ("completion_min_quantile", C.c_double), ("score_w_delta_db", C.c_double), ("abs_gain_min_db", C.c_double),
+        ("qos_soft_penalty", C.c_double), ("qos_R_min", C.c_double), ("noise_power", C.c_double),
+        ("P_max", C.c_double), ("relax_tau_factor", C.c_double), ("tau_back_floor_db", C.c_double),
+        ("freeze_reward_drop_ratio", C.c_double), ("freeze_unstick_prob", C.c_double),
+        ("score_w_history", C.c_float), ("pair_hist_decay", C.c_float),
+    ]
+
+
+class RisVecNomaState(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32), ("n_veh", C.c_int32), ("env_offset", C.c_int64),
+        ("hist", _FP), ("streak", _FP), ("partner", _FP), ("n_groups", _FP), ("last_global", _FP),
+        ("best_global", _FP), ("flags", _FP), ("mask", _FP), ("tau", _FP), ("scratch", _FP),
+        ("scratch_bytes", C.c_uint64),
+    ]
+
+
+NOMA_MAX_VEH = 16
+NOMA_HAS_LAST, NOMA_UNSTICK_USED, NOMA_HAS_GROUPS = 1, 2, 4
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librisvec.so")
 
 _PROTOS = {
@@ -105,6 +131,12 @@ _PROTOS = {
                                    C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
     "risvec_step_fused_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP,
                                         _FP, _FP, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
+    "risvec_noma_default_params": (None, [C.POINTER(RisVecNomaParams), C.c_int32]),
+    "risvec_noma_begin_episode": (C.c_int, [C.POINTER(RisVecNomaState), _FP]),
+    "risvec_noma_mask": (C.c_int, [C.POINTER(RisVecNomaState), _FP, _FP, C.c_double, C.c_int32, _FP]),
+    "risvec_noma_group": (C.c_int, [C.POINTER(RisVecNomaState), C.POINTER(RisVecNomaParams), _FP, _FP, _FP,
+                                    C.c_int32, C.c_double, C.c_int32, _FP, _FP, C.c_int32, C.c_int32, _FP,
+                                    C.c_uint64, C.c_uint32, _FP, _FP, _FP, _FP]),
 }
 
 EXPORTS = tuple(_PROTOS)   # every symbol include/risvec.h declares

@@ -298,4 +298,94 @@ int risvec_step_fused_bcd(const RisVecState* s, const RisVecParams* p, const flo
                                                     counter, flags, (hipStream_t)stream));
 }
 
+// ---------------------------------------------------------------------------------------------
+// NOMA grouping stage (f2)
+// ---------------------------------------------------------------------------------------------
+void risvec_noma_default_params(RisVecNomaParams* p, int32_t n_veh) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->min_pair_target = n_veh / 4 > 1 ? n_veh / 4 : 1;               // TRAIN:489
+    p->mwm_backoff_rounds = 5; p->mwm_allow_singles = 1;               // TRAIN:440, 436
+    p->qos_enable = 0; p->relax_topk_step = 1;                         // TRAIN:750 (Config default), 728
+    p->freeze_group_in_episode = 1; p->freeze_recalc_every = 0;        // TRAIN:738-739
+    p->mask_enable = 1;                                                // TRAIN:498
+    p->mwm_accept_quantile = 0.10; p->mwm_accept_q_step = 0.05;        // TRAIN:439, 441
+    p->completion_min_quantile = 0.30;                                 // TRAIN:282
+    p->score_w_delta_db = 1.0; p->score_w_history = 0.3f;              // TRAIN:716-717
+    p->abs_gain_min_db = -HUGE_VAL;                                    // TRAIN:723
+    p->qos_soft_penalty = 6.0; p->qos_R_min = 0.0;                     // TRAIN:172, 751
+    p->noise_power = std::pow(10.0, -174.0 / 10.0) / 1000.0 * 1.0e6;   // ENV:72-76
+    p->P_max = 1.0;                                                    // ENV:125
+    p->relax_tau_factor = 0.95; p->tau_back_floor_db = 3.0;            // TRAIN:729, 1499
+    p->freeze_reward_drop_ratio = 0.05; p->freeze_unstick_prob = 0.0;  // TRAIN:741, 740
+    p->pair_hist_decay = 0.97f;                                        // TRAIN:719
+}
+
+static int check_noma(const char* fn, const RisVecNomaState* ns) {
+    if (!ns) return fail(RISVEC_ERR_ARG, "%s: noma state is NULL", fn);
+    if (ns->n_envs < 1) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d must be >= 1", fn, ns->n_envs);
+    if (ns->n_veh < 1 || ns->n_veh > RISVEC_NOMA_MAX_VEH)
+        return fail(RISVEC_ERR_SHAPE, "%s: n_veh=%d outside [1,%d]", fn, ns->n_veh, RISVEC_NOMA_MAX_VEH);
+    if (ns->env_offset < 0 || ns->env_offset + ns->n_envs > 0xFFFFFFFFLL)
+        return fail(RISVEC_ERR_SHAPE, "%s: env_offset+n_envs must fit 32 bits", fn);
+    return RISVEC_OK;
+}
+
+int risvec_noma_begin_episode(const RisVecNomaState* ns, risvec_stream_t stream) {
+    const char* fn = "risvec_noma_begin_episode";
+    if (int rc = check_noma(fn, ns)) return rc;
+    REQ_PTR(ns->hist, "noma.hist"); REQ_PTR(ns->streak, "noma.streak"); REQ_PTR(ns->flags, "noma.flags");
+    return finish(fn, risvec::launch_noma_begin_episode(*ns, (hipStream_t)stream));
+}
+
+int risvec_noma_mask(const RisVecNomaState* ns, const float* gain, const double* gdb15, double q_now, int32_t K_now,
+                     risvec_stream_t stream) {
+    const char* fn = "risvec_noma_mask";
+    if (int rc = check_noma(fn, ns)) return rc;
+    OPT_PTR(gdb15, "gdb15");
+    if (!gdb15) REQ_PTR(gain, "gain");
+    REQ_PTR(ns->tau, "noma.tau");
+    if (K_now >= 1) REQ_PTR(ns->mask, "noma.mask");
+    if (!(q_now >= 0.0 && q_now <= 1.0)) return fail(RISVEC_ERR_ARG, "%s: q_now=%g outside [0,1]", fn, q_now);
+    return finish(fn, risvec::launch_noma_mask(*ns, gain, gdb15, q_now, K_now, (hipStream_t)stream));
+}
+
+int risvec_noma_group(const RisVecNomaState* ns, const RisVecNomaParams* np, const float* gain, const double* gdb12,
+                      const float* p_off01, int32_t use_mask, double q_back, int32_t K_back, const double* tau_back,
+                      const float* prev_global, int32_t prev_global_stride, int32_t i_step, const float* u_unstick,
+                      uint64_t seed, uint32_t counter, int32_t* partner_out, int32_t* n_groups_out, int32_t* info_out,
+                      risvec_stream_t stream) {
+    const char* fn = "risvec_noma_group";
+    if (int rc = check_noma(fn, ns)) return rc;
+    if (!np) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    REQ_PTR(gain, "gain"); OPT_PTR(gdb12, "gdb12"); OPT_PTR(p_off01, "p_off01"); REQ_PTR(tau_back, "tau_back");
+    OPT_PTR(u_unstick, "u_unstick"); REQ_PTR(partner_out, "partner_out"); REQ_PTR(n_groups_out, "n_groups_out");
+    OPT_PTR(info_out, "info_out");
+    REQ_PTR(ns->hist, "noma.hist"); REQ_PTR(ns->streak, "noma.streak"); REQ_PTR(ns->partner, "noma.partner");
+    REQ_PTR(ns->n_groups, "noma.n_groups"); REQ_PTR(ns->last_global, "noma.last_global");
+    REQ_PTR(ns->best_global, "noma.best_global"); REQ_PTR(ns->flags, "noma.flags");
+    if (np->qos_enable && !p_off01) return fail(RISVEC_ERR_ARG, "%s: qos_enable needs p_off01", fn);
+    if (np->mask_enable && use_mask) REQ_PTR(ns->mask, "noma.mask");
+    if (prev_global && prev_global_stride < 1)
+        return fail(RISVEC_ERR_ARG, "%s: prev_global_stride=%d must be >= 1", fn, prev_global_stride);
+    if (prev_global && (reinterpret_cast<uintptr_t>(prev_global) & 3u))
+        return fail(RISVEC_ERR_ARG, "%s: prev_global is not 4-byte aligned", fn);
+    if (K_back < 0) return fail(RISVEC_ERR_ARG, "%s: K_back=%d must be >= 0", fn, K_back);
+    if (np->mwm_backoff_rounds < 0 || np->mwm_backoff_rounds > 64)
+        return fail(RISVEC_ERR_ARG, "%s: mwm_backoff_rounds=%d outside [0,64]", fn, np->mwm_backoff_rounds);
+    int slots = 0;
+    if (ns->n_veh > 12) {       // the matching table of > 12 matchable users does not fit LDS
+        const uint64_t per_env = 8ull << ns->n_veh;
+        if (!ns->scratch || ns->scratch_bytes < per_env)
+            return fail(RISVEC_ERR_ARG, "%s: n_veh=%d needs noma.scratch of at least %llu bytes", fn, ns->n_veh,
+                        (unsigned long long)per_env);
+        REQ_PTR(ns->scratch, "noma.scratch");
+        const uint64_t fit = ns->scratch_bytes / per_env;
+        slots = (int)(fit > 1024 ? 1024 : fit);
+    }
+    return finish(fn, risvec::launch_noma_group(*ns, *np, gain, gdb12, p_off01, use_mask, q_back, K_back, tau_back,
+                                                prev_global, prev_global_stride, i_step, u_unstick, seed, counter,
+                                                partner_out, n_groups_out, info_out, slots, (hipStream_t)stream));
+}
+
 }  // extern "C"
