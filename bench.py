@@ -167,6 +167,9 @@ def main() -> None:
     ap.add_argument("--mode", default="fused", choices=["fused", "cached", "bcd"],
                     help="fused: gains+step each step (headline); cached: step only (reference cadence); "
                          "bcd: BCD sweep + gains + step each step (BASELINE config 5)")
+    ap.add_argument("--noma", action="store_true",
+                    help="also run the NOMA grouping stage (SURVEY 8 f2) before every step, with the reference's "
+                         "episode structure: 100-step episodes, mask rebuilt at step 0, groups frozen in between")
     args = ap.parse_args()
 
     from ris_vec_marl_amd import dist as rdist
@@ -206,10 +209,32 @@ def main() -> None:
     full = not args.lean
 
     # arguments validated and marshalled once; each call is then a single C-ABI launch
+    grouper = None
+    if args.noma:
+        from ris_vec_marl_amd import NomaGrouper
+        grouper = NomaGrouper(env)
+        grouper.config.apply_yaml({"min_pair_target": 3, "mwm_backoff_rounds": 3, "qos_enable": True,
+                                   "reward": {"mask_topk_start": 7, "mask_topk_end": 7, "mask_tau_q_start": 0.10,
+                                              "mask_tau_q_end": 0.25, "pairing_threshold_quantile": 0.25}})
+        if not fused:
+            env.update_channel_gains()
+        else:
+            env.bind_step(action, partner, n_groups, None, fused=True, metrics=full, power_w=False, obs=full)()
+        grouper.begin_episode(0); grouper.refresh_mask()
+        partner, n_groups = grouper.group(action[:, 0, :].contiguous(), 0)     # state views: stable pointers
+    p_off01 = action[:, 0, :].contiguous()
+    group = grouper.bind_group(p_off01) if grouper is not None else None
     launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full, power_w=False,
                            obs=full)
+    episode_len = 100
 
     def one_step(i: int) -> None:
+        if grouper is not None:
+            t = i % episode_len
+            if t == 0:
+                grouper.begin_episode(i // episode_len)
+                grouper.refresh_mask()
+            group(t)
         launch()
         if gather is not None and i % args.gather_every == 0:
             gather.start(env.tensors["obs"])
@@ -270,10 +295,12 @@ def main() -> None:
                                "fp32/complex64, %s every step, metrics+obs %s, Philox arrivals"
                                % (4 if bcd else 2, E, V, M, workload, "written" if full else "off"),
                    "envs_per_gpu": E, "n_veh": V, "n_ris": M, "mode": args.mode, "allgather": gather_note,
+                   "noma_grouping": ("device, every step, 100-step episodes (config.yaml pairing keys)"
+                                     if args.noma else "synthetic fixed groups"),
                    "agent_steps_per_s": E * world * args.steps / dt * V},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"fused": "k_step_fused_pipe<8,64,2>" if (V, M) == (8, 64) else "k_step_fused*",
+                     "kernel": {"fused": "k_step_fused_pipe<8,64,2,MarlCore>" if (V, M) == (8, 64) else "k_step_fused*",
                                 "cached": "k_step", "bcd": "k_bcd_lane + k_step_fused*"}[args.mode],
                      "algorithmic_bytes_per_env_step": per_env, "bytes_per_launch": bytes_per_launch,
                      "avg_launch_ms": kernel_ms},

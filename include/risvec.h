@@ -325,26 +325,31 @@ enum RisVecNomaFlag {               /* bits of RisVecNomaState.flags[e]         
     RISVEC_NOMA_HAS_GROUPS = 4      /* episode_groups is set (TRAIN:1297, 1552)             */
 };
 
-/* Episode-scoped state of TRAIN:1282-1300, device pointers, N = n_veh. */
+/* Episode-scoped state of TRAIN:1282-1300, device pointers, N = n_veh.  Most steps of an episode
+ * are frozen steps (TRAIN:1542-1547): for those risvec_noma_group only counts the step in `pending`;
+ * the history decay / pair increments (TRAIN:1406, 1556-1558) and streak updates (TRAIN:1560-1561)
+ * they owe are replayed, operation for operation, when the env next re-solves its pairing or when
+ * risvec_noma_flush is called.  hist / streak are therefore current only after a flush; partner /
+ * n_groups / flags always are. */
 typedef struct RisVecNomaState {
     int32_t n_envs, n_veh;
     int64_t env_offset;             /* global id of local env 0 (RNG key)                   */
     float *hist;                    /* [E,N,N] pair_affinity_hist                           */
     int32_t *streak;                /* [E,N]   unpaired_streak                              */
-    int32_t *partner;               /* [E,N]   episode_groups, partner encoding of risvec_step */
+    int32_t *partner;               /* [E,N]   episode_groups = this step's noma_groups, partner encoding of risvec_step */
     int32_t *n_groups;              /* [E]     len(episode_groups)                          */
     double *last_global;            /* [E]     last_env_global                              */
     double *best_global;            /* [E]     ep_env_best                                  */
     uint8_t *flags;                 /* [E]     RisVecNomaFlag bits                          */
     uint8_t *mask;                  /* [E,N,N] last_mask_mat (0/1)                          */
     double *tau;                    /* [E]     last_tau_now                                 */
-    double *scratch;                /* matching table spill for > 12 matchable users; may be NULL when n_veh <= 12 */
-    uint64_t scratch_bytes;         /* >= 8 << n_veh bytes per concurrently resident env (library uses as many as fit, <= 1024) */
+    int32_t *pending;               /* [E]     frozen steps not yet applied to hist / streak */
+    int32_t *todo;                  /* [E+2]   work list of one group() call + 2 control words; zero it once at allocation */
 } RisVecNomaState;
 
 void risvec_noma_default_params(RisVecNomaParams *p, int32_t n_veh);   /* driver Config defaults */
 
-/* Start of an episode (TRAIN:1282-1300): zero hist / streak / flags. */
+/* Start of an episode (TRAIN:1282-1300): zero hist / streak / flags / pending. */
 int risvec_noma_begin_episode(const RisVecNomaState *ns, risvec_stream_t stream);
 
 /* Channel-refresh step (TRAIN:1319-1343): tau = quantile q_now of |g_strong - g_weak| in dB
@@ -354,22 +359,25 @@ int risvec_noma_begin_episode(const RisVecNomaState *ns, risvec_stream_t stream)
 int risvec_noma_mask(const RisVecNomaState *ns, const float *gain, const double *gdb15, double q_now,
                      int32_t K_now, risvec_stream_t stream);
 
-/* One pass of TRAIN:1401-1562 for every env.
+/* One pass of TRAIN:1401-1562 for every env; this step's noma_groups are left in ns->partner /
+ * ns->n_groups, ready for risvec_step*.
  *   gain [E,N] f32; gdb12 [E,N] f64 = 10 log10(max(g, 1e-12)) or NULL; p_off01 [E,N] f32 = the
  *   offload power in [0,1] used by the QoS check (TRAIN:1391-1396; may be NULL when qos is off);
  *   use_mask: this step's mask_mat is ns->mask (a refresh step) / 0 = None (TRAIN:1421-1424);
- *   q_back, K_back, tau_back [E]: last_q_now / last_K_now / last_tau_now (TRAIN:1486-1491);
+ *   K_back, tau_back [E]: last_K_now / last_tau_now (TRAIN:1486-1491; last_q_now only feeds a
+ *   value the reference computes and never uses, TRAIN:1497);
  *   prev_global (stride in floats) or NULL: global reward of the PREVIOUS step -- the
  *   ep_env_best / last_env_global bookkeeping of TRAIN:1618-1623 is applied first;
  *   u_unstick [E] f32 or NULL (Philox) : the draw of TRAIN:1539;
- *   partner_out [E,N], n_groups_out [E]: this step's noma_groups for risvec_step*;
  *   info_out [E,4] or NULL: {recomputed, back-off rounds, pairs, matchable users of the last matching}. */
 int risvec_noma_group(const RisVecNomaState *ns, const RisVecNomaParams *np, const float *gain,
-                      const double *gdb12, const float *p_off01, int32_t use_mask, double q_back,
-                      int32_t K_back, const double *tau_back, const float *prev_global,
-                      int32_t prev_global_stride, int32_t i_step, const float *u_unstick, uint64_t seed,
-                      uint32_t counter, int32_t *partner_out, int32_t *n_groups_out, int32_t *info_out,
-                      risvec_stream_t stream);
+                      const double *gdb12, const float *p_off01, int32_t use_mask, int32_t K_back,
+                      const double *tau_back, const float *prev_global, int32_t prev_global_stride,
+                      int32_t i_step, const float *u_unstick, uint64_t seed, uint32_t counter,
+                      int32_t *info_out, risvec_stream_t stream);
+
+/* Apply the deferred frozen steps to hist / streak (pair_hist_decay = np->pair_hist_decay). */
+int risvec_noma_flush(const RisVecNomaState *ns, const RisVecNomaParams *np, risvec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -96,8 +96,7 @@ class RisVecNomaState(C.Structure):
     _fields_ = [
         ("n_envs", C.c_int32), ("n_veh", C.c_int32), ("env_offset", C.c_int64),
         ("hist", _FP), ("streak", _FP), ("partner", _FP), ("n_groups", _FP), ("last_global", _FP),
-        ("best_global", _FP), ("flags", _FP), ("mask", _FP), ("tau", _FP), ("scratch", _FP),
-        ("scratch_bytes", C.c_uint64),
+        ("best_global", _FP), ("flags", _FP), ("mask", _FP), ("tau", _FP), ("pending", _FP), ("todo", _FP),
     ]
 
 
@@ -135,8 +134,9 @@ _PROTOS = {
     "risvec_noma_begin_episode": (C.c_int, [C.POINTER(RisVecNomaState), _FP]),
     "risvec_noma_mask": (C.c_int, [C.POINTER(RisVecNomaState), _FP, _FP, C.c_double, C.c_int32, _FP]),
     "risvec_noma_group": (C.c_int, [C.POINTER(RisVecNomaState), C.POINTER(RisVecNomaParams), _FP, _FP, _FP,
-                                    C.c_int32, C.c_double, C.c_int32, _FP, _FP, C.c_int32, C.c_int32, _FP,
-                                    C.c_uint64, C.c_uint32, _FP, _FP, _FP, _FP]),
+                                    C.c_int32, C.c_int32, _FP, _FP, C.c_int32, C.c_int32, _FP,
+                                    C.c_uint64, C.c_uint32, _FP, _FP]),
+    "risvec_noma_flush": (C.c_int, [C.POINTER(RisVecNomaState), C.POINTER(RisVecNomaParams), _FP]),
 }
 
 EXPORTS = tuple(_PROTOS)   # every symbol include/risvec.h declares

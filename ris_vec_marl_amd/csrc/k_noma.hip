@@ -5,20 +5,28 @@
 // check (TRAIN:858-880) and the control logic with the freeze-in-episode safeties
 // (TRAIN:1401-1562, 1618-1623).
 //
-// Work decomposition: ONE WAVEFRONT PER ENV (workgroup = 64 lanes), grid-stride over envs.  The
-// N x N matrices (N <= 16) live in LDS with the entries dealt round-robin to the lanes; every
-// decision the reference takes by comparing float64 numbers is taken here by comparing float64
-// numbers formed in the same association order (fp contraction is off for the whole file: the
-// matcher's exact ties are decided by last-bit rounding).
+// Three kernels per group() call, because almost every step of an episode is a FROZEN step:
+//   k_noma_pre    one lane per env: reward bookkeeping (TRAIN:1618-1623), the freeze decision
+//                 (TRAIN:1527-1540); frozen envs only bump `pending` (their history decay / pair
+//                 increments and streak updates are replayed, operation for operation, the next time
+//                 somebody needs them), the others are appended to a compact to-do list;
+//   k_noma_solve  ONE WAVEFRONT PER LISTED ENV (workgroup = 64 lanes): replay, then the pairing;
+//   k_noma_flush  materialises `pending` for readers of the history / streak tensors.
+// In the solve kernel the N x N matrices (N <= 16) live in LDS with the entries dealt round-robin to
+// the lanes; every decision the reference takes by comparing float64 numbers is taken by comparing
+// float64 numbers formed in the same association order (fp contraction is off for the whole file:
+// the matcher's exact ties are decided by last-bit rounding).
 //   * quantiles: no sort -- each lane ranks its own entries against all (LDS broadcast reads) and
 //     the two order statistics NumPy's linear method interpolates are picked by rank;
-//   * matching: the reference's memoised recursion on the lowest unused user, evaluated bottom-up
-//     over bitmasks in popcount layers (a mask only needs masks with 1 or 2 more bits), after
-//     dropping users without any admissible edge (they pass the value through unchanged); table
-//     in LDS up to 2^KL entries, in a caller-provided HBM slot beyond;
+//   * matching: the reference's memoised recursion on the lowest unused user x, evaluated bottom-up
+//     in layers of x (a state only needs states with a larger x), after dropping users without any
+//     admissible edge (they pass the value through unchanged).  Only states the recursion can reach
+//     are stored: with x the lowest unused user at most x users above it are taken, which leaves
+//     2 583 of the 65 536 masks at 16 users; they are indexed by (x, size, colex rank) so the table
+//     fits LDS for every K <= 16;
 //   * completion: repeated wave-wide arg-max over the still-free admissible edges, which is what
 //     the reference's sorted greedy scan selects.
-// This is integer / branchy float64 work of a few KB per env; it is latency-bound, not HBM-bound.
+// This is integer / branchy float64 work of a few hundred bytes per env; it is latency-bound.
 #include "risvec_launch.hpp"
 
 #pragma clang fp contract(off)
@@ -27,10 +35,9 @@ namespace risvec {
 namespace {
 
 constexpr int kNV = RISVEC_NOMA_MAX_VEH;
-constexpr int kNN = kNV * kNV;
-constexpr int kEPL = kNN / kWave;                   // matrix entries per lane (4)
 constexpr uint32_t kSiteUnstick = 7;                // Philox site of the TRAIN:1539 draw
 constexpr double kInf = __builtin_huge_val();
+constexpr int kBinW = 9;                            // binomials C(c, i), c < 16, i <= 8
 
 struct NomaArgs {
     RisVecNomaState ns;
@@ -39,7 +46,6 @@ struct NomaArgs {
     const double* gdb12;
     const float* p01;
     int use_mask;
-    double q_back;
     int K_back;
     const double* tau_back;
     const float* prev_global;
@@ -48,8 +54,6 @@ struct NomaArgs {
     const float* u_unstick;
     uint64_t seed;
     uint32_t counter;
-    int32_t* partner_out;
-    int32_t* n_groups_out;
     int32_t* info_out;
 };
 
@@ -64,30 +68,125 @@ __device__ __forceinline__ int wave_sum(int x) {
     return x;
 }
 __device__ __forceinline__ bool finite(double x) { return fabs(x) < kInf; }
+__device__ __forceinline__ bool is_first(int p) { return p >= 0 && p < 65536; }
+__device__ __forceinline__ bool paired_with(int p, int j) { return p >= 0 && (p & 0xFFFF) == j; }
 
-// Rank bookkeeping of one lane's entries within the multiset {val[k] : ok[k]}.
+// One deferred frozen step on a history entry / a streak (TRAIN:1406, 1556-1561).
+__device__ __forceinline__ float replay_hist(float h, int pending, float decay, bool pair) {
+    for (int k = 0; k < pending; ++k) {
+        h = h * decay;
+        if (pair) h += 1.0f;
+    }
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pre: one lane per env
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_noma_pre(NomaArgs A) {
+    const int env = blockIdx.x * kBlock + threadIdx.x;
+    if (env >= A.ns.n_envs) return;
+    const RisVecNomaParams& P = A.P;
+    int flags = A.ns.flags[env];
+    double last = A.ns.last_global[env], best = A.ns.best_global[env];
+    if (A.prev_global) {                               // TRAIN:1618-1623, for the step that just ran
+        const double g = (double)A.prev_global[(long long)env * A.prev_stride];
+        if (!(flags & RISVEC_NOMA_HAS_LAST)) best = g;
+        else if (g > best) best = g;
+        last = g;
+        flags |= RISVEC_NOMA_HAS_LAST;
+        A.ns.last_global[env] = last;
+        A.ns.best_global[env] = best;
+    }
+    const bool frozen = P.freeze_group_in_episode && (flags & RISVEC_NOMA_HAS_GROUPS);
+    bool need_repair = false;
+    if (frozen) {                                      // TRAIN:1527-1540
+        if (P.freeze_recalc_every > 0 && A.i_step % P.freeze_recalc_every == 0) need_repair = true;
+        if (!need_repair && (flags & RISVEC_NOMA_HAS_LAST) && !(flags & RISVEC_NOMA_UNSTICK_USED)) {
+            if (last < best * (1.0 - P.freeze_reward_drop_ratio)) {
+                need_repair = true;
+                flags |= RISVEC_NOMA_UNSTICK_USED;
+            }
+        }
+        if (!need_repair && P.freeze_unstick_prob > 0.0) {
+            const double u = A.u_unstick
+                ? (double)A.u_unstick[env]
+                : (double)u01(philox4x32_10((uint32_t)(A.ns.env_offset + env), 0u, A.counter, kSiteUnstick, A.seed).x);
+            if (u < P.freeze_unstick_prob) need_repair = true;
+        }
+    }
+    A.ns.flags[env] = (uint8_t)flags;
+    if (frozen && !need_repair) {                      // reuse episode_groups (TRAIN:1542-1547): defer the bookkeeping
+        A.ns.pending[env] += 1;
+        if (A.info_out) {
+            int* o = A.info_out + (long long)env * 4;
+            o[0] = 0; o[1] = 0; o[2] = A.ns.n_veh - A.ns.n_groups[env]; o[3] = 0;
+        }
+    } else {
+        const int k = atomicAdd(A.ns.todo + A.ns.n_envs, 1);
+        A.ns.todo[k] = env;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// flush: materialise the deferred frozen steps (one lane per matrix entry)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_noma_flush(RisVecNomaState ns, float decay) {
+    const int N = ns.n_veh, NN = N * N;
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (long long)ns.n_envs * NN) return;
+    const int env = (int)(gid / NN), idx = (int)(gid % NN), i = idx / N, j = idx % N;
+    const int pend = ns.pending[env];
+    if (pend == 0) return;
+    const int p = ns.partner[(long long)env * N + i];
+    ns.hist[gid] = replay_hist(ns.hist[gid], pend, decay, paired_with(p, j));
+    if (j == 0) {
+        int* st = ns.streak + (long long)env * N + i;
+        *st = p >= 0 ? 0 : *st + pend;
+    }
+}
+__global__ void __launch_bounds__(kBlock)
+k_noma_clear_pending(RisVecNomaState ns) {
+    const int env = blockIdx.x * kBlock + threadIdx.x;
+    if (env < ns.n_envs) ns.pending[env] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// solve: one wavefront per env of the to-do list
+// ---------------------------------------------------------------------------------------------
+template <int NMAX>
+struct Shape {
+    static constexpr int NN = NMAX * NMAX;
+    static constexpr int EPL = NN / kWave;             // matrix entries per lane
+    static constexpr int DP = NMAX <= 8 ? 256 : 2600;  // matching table: 2^8 masks / the 2 583 reachable states at 16
+    static constexpr int KPLAIN = NMAX <= 8 ? 8 : 11;  // up to here the table is simply indexed by the mask
+};
+
+template <int EPL>
 struct Ranks {
-    double x[kEPL];
-    int less[kEPL], leq[kEPL];
-    bool ok[kEPL];
+    double x[EPL];
+    int less[EPL], leq[EPL];
     int cnt;
 };
 
-__device__ __forceinline__ void rank_entries(const double* val, const uint8_t* ok, int n, int lane, Ranks& R) {
+// val[k] = +inf for entries outside the multiset, so they rank after everything.
+template <int EPL>
+__device__ __forceinline__ void rank_entries(const double* val, int n, int lane, Ranks<EPL>& R) {
     int mine = 0;
 #pragma unroll
-    for (int t = 0; t < kEPL; ++t) {
+    for (int t = 0; t < EPL; ++t) {
         const int idx = lane + t * kWave;
-        R.ok[t] = idx < n && ok[idx];
-        R.x[t] = R.ok[t] ? val[idx] : 0.0;
+        R.x[t] = idx < n ? val[idx] : kInf;
         R.less[t] = R.leq[t] = 0;
-        mine += R.ok[t] ? 1 : 0;
+        mine += R.x[t] < kInf ? 1 : 0;
     }
+#pragma unroll 8
     for (int k = 0; k < n; ++k) {                     // broadcast reads: every lane the same address
-        if (!ok[k]) continue;
         const double y = val[k];
 #pragma unroll
-        for (int t = 0; t < kEPL; ++t) {
+        for (int t = 0; t < EPL; ++t) {
             R.less[t] += y < R.x[t] ? 1 : 0;
             R.leq[t] += y <= R.x[t] ? 1 : 0;
         }
@@ -95,18 +194,19 @@ __device__ __forceinline__ void rank_entries(const double* val, const uint8_t* o
     R.cnt = wave_sum(mine);
 }
 
-// k-th smallest (0-based) of the ranked multiset.
-__device__ __forceinline__ double order_stat(const Ranks& R, int k) {
+template <int EPL>
+__device__ __forceinline__ double order_stat(const Ranks<EPL>& R, int k) {   // k-th smallest, 0-based
     double v = -kInf;
 #pragma unroll
-    for (int t = 0; t < kEPL; ++t)
-        if (R.ok[t] && R.less[t] <= k && k < R.leq[t]) v = R.x[t];
+    for (int t = 0; t < EPL; ++t)
+        if (R.x[t] < kInf && R.less[t] <= k && k < R.leq[t]) v = R.x[t];
     return wave_max(v);
 }
 
 // np.quantile(values, q), method 'linear': virtual index (n-1) q, neighbours floor / floor+1 (both
 // the last element from n-1 up), two-sided lerp (a + d t below t = 0.5, b - d (1-t) from there).
-__device__ __forceinline__ double quantile_linear(const Ranks& R, double q) {
+template <int EPL>
+__device__ __forceinline__ double quantile_linear(const Ranks<EPL>& R, double q) {
     const int n = R.cnt;
     const double vi = (double)(n - 1) * q;
     int lo = (int)floor(vi), hi;
@@ -121,297 +221,351 @@ __device__ __forceinline__ double quantile_linear(const Ranks& R, double q) {
     return r;
 }
 
-// Value and choice of the matching recurrence at `mask` (TRAIN:360-391): lowest unused user x stays
-// single (arg -1) or takes partner j (arg j); arg -2 = no option (value 0, nothing below it).
-__device__ __forceinline__ double best_at(const double* T, const double* w, int K, bool singles, int mask,
-                                          int& arg) {
+// Matching table: value of the recurrence at a reachable mask.  x = lowest unused user, T = users
+// taken above x (|T| <= x); slot = base[x] + (number of smaller subsets of the K-1-x upper users)
+// + colex rank of T among the subsets of its size.
+struct MatchTab {
+    const double* dp;
+    const int* base;       // [K+1]
+    const int* binom;      // [16][kBinW]
+    const int* sizeoff;    // [16][kBinW + 1]
+    int K, full;
+    bool plain;            // 2^K fits the table: slot = mask (no ranking arithmetic on the critical path)
+    __device__ __forceinline__ int slot(int mask) const {
+        if (plain) return mask;
+        const int x = __ffs(~mask) - 1;
+        unsigned T = (unsigned)mask >> (x + 1);
+        const int n = K - 1 - x;
+        int r = base[x] + sizeoff[n * (kBinW + 1) + __popc(T)];
+        for (int i = 1; T; ++i, T &= T - 1) r += binom[(__ffs(T) - 1) * kBinW + i];
+        return r;
+    }
+    __device__ __forceinline__ double value(int mask) const { return mask == full ? 0.0 : dp[slot(mask)]; }
+};
+
+// Value and choice of the recurrence at `mask` (TRAIN:360-391): the lowest unused user x stays single
+// (arg -1) or takes partner j (arg j); arg -2 = no option (value 0, nothing below it).
+__device__ __forceinline__ double best_at(const MatchTab& M, const double* w, bool singles, int mask, int& arg) {
     const int x = __ffs(~mask) - 1;
     double best = -kInf;
     arg = -2;
     if (singles) {
-        const double w1 = T[mask | (1 << x)];
+        const double w1 = M.value(mask | (1 << x));
         if (w1 > best) { best = w1; arg = -1; }
     }
-    for (int j = x + 1; j < K; ++j) {
+    for (int j = x + 1; j < M.K; ++j) {
         if ((mask >> j) & 1) continue;
         const double we = w[x * kNV + j];
         if (!finite(we)) continue;
-        const double w2 = T[mask | (1 << x) | (1 << j)];
+        const double w2 = M.value(mask | (1 << x) | (1 << j));
         if (finite(w2) && we + w2 > best) { best = we + w2; arg = j; }
     }
     return best;
 }
 
-template <int KL>
+template <int NMAX>
 __global__ void __launch_bounds__(kWave)
-k_noma_group(NomaArgs A) {
-    __shared__ double s_S[kNN], s_W[kNN], s_w[kNN], s_g[kNV], s_lin[kNV], s_p[kNV], s_dp[1 << KL];
-    __shared__ float s_hist[kNN];
-    __shared__ uint8_t s_feas[kNN], s_ok[kNN], s_qos[kNN];
-    __shared__ int s_part[kNV];
+k_noma_solve(NomaArgs A) {
+    using S = Shape<NMAX>;
+    constexpr int EPL = S::EPL;
+    __shared__ double s_S[S::NN], s_R[S::NN], s_W[S::NN], s_w[kNV * kNV], s_g[kNV], s_lin[kNV], s_p[kNV];
+    __shared__ double s_dp[S::DP];
+    __shared__ float s_hist[S::NN];
+    __shared__ uint8_t s_feas[S::NN], s_qos[S::NN];
+    __shared__ int s_part[kNV], s_base[kNV + 1], s_binom[16 * kBinW], s_sizeoff[16 * (kBinW + 1)];
+    __shared__ signed char s_arg[S::DP];               // choice taken at each state, for the walk-back
     const int lane = threadIdx.x;
-    const int N = A.ns.n_veh, NN = N * N, E = A.ns.n_envs;
+    const int N = A.ns.n_veh, NN = N * N;
     const RisVecNomaParams& P = A.P;
     const bool singles = P.mwm_allow_singles != 0;
 
-    for (int env = blockIdx.x; env < E; env += gridDim.x) {
+    // Most calls find an empty or short list (frozen steps): blocks without work skip straight to the exit.
+    const int n_todo = A.ns.todo[A.ns.n_envs];
+    if ((int)blockIdx.x < n_todo) {
+    // binomials C(c, i) and their prefix sums over i (Pascal rows; one row per lane)
+    if (lane < 16) {
+        int c = 1;                                     // C(lane, 0)
+        int off = 0;
+        for (int i = 0; i <= kBinW; ++i) {
+            if (i < kBinW) s_binom[lane * kBinW + i] = c;
+            s_sizeoff[lane * (kBinW + 1) + i] = off;
+            off += c;
+            c = i < lane ? c * (lane - i) / (i + 1) : 0;   // C(lane, i+1)
+        }
+    }
+    // this lane's matrix entries
+    int ei[EPL], ej[EPL];
+    bool ein[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int idx = lane + t * kWave;
+        ein[t] = idx < NN;
+        ei[t] = ein[t] ? idx / N : 0;
+        ej[t] = ein[t] ? idx % N : 0;
+    }
+    for (int item = blockIdx.x; item < n_todo; item += gridDim.x) {
+        const int env = A.ns.todo[item];
         __syncthreads();                               // LDS reuse across envs
-        // ---- ep_env_best / last_env_global of the previous step (TRAIN:1618-1623) ----------
-        int flags = A.ns.flags[env];
-        double last = A.ns.last_global[env], best = A.ns.best_global[env];
-        if (A.prev_global) {
-            const double g = (double)A.prev_global[(long long)env * A.prev_stride];
-            if (!(flags & RISVEC_NOMA_HAS_LAST)) best = g;
-            else if (g > best) best = g;
-            last = g;
-            flags |= RISVEC_NOMA_HAS_LAST;
-        }
-        // ---- history decay, float32 in place (TRAIN:1406) ------------------------------------
+        const int flags = A.ns.flags[env];
+        const int pend = A.ns.pending[env];
+        const bool had_groups = (flags & RISVEC_NOMA_HAS_GROUPS) != 0;
         float* hist = A.ns.hist + (long long)env * NN;
-        for (int idx = lane; idx < NN; idx += kWave) s_hist[idx] = hist[idx] * P.pair_hist_decay;
-        // ---- freeze-in-episode with its three safeties (TRAIN:1527-1540) -----------------------
-        const bool frozen = P.freeze_group_in_episode && (flags & RISVEC_NOMA_HAS_GROUPS);
-        bool need_repair = false;
-        if (frozen) {
-            if (P.freeze_recalc_every > 0 && A.i_step % P.freeze_recalc_every == 0) need_repair = true;
-            if (!need_repair && (flags & RISVEC_NOMA_HAS_LAST) && !(flags & RISVEC_NOMA_UNSTICK_USED)) {
-                if (last < best * (1.0 - P.freeze_reward_drop_ratio)) {
-                    need_repair = true;
-                    flags |= RISVEC_NOMA_UNSTICK_USED;
+        if (lane < N) {
+            const double g = (double)A.gain[(long long)env * N + lane];
+            s_lin[lane] = g;
+            s_g[lane] = A.gdb12 ? A.gdb12[(long long)env * N + lane] : 10.0 * log10(fmax(g, 1e-12));
+            s_p[lane] = A.p01 ? (double)A.p01[(long long)env * N + lane] : 0.0;
+            s_part[lane] = had_groups ? A.ns.partner[(long long)env * N + lane] : -1;
+        }
+        __syncthreads();
+        // deferred frozen steps with the OLD groups, then this step's decay (TRAIN:1406)
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            if (!ein[t]) continue;
+            const int idx = lane + t * kWave;
+            float h = replay_hist(hist[idx], pend, P.pair_hist_decay, had_groups && paired_with(s_part[ei[t]], ej[t]));
+            s_hist[idx] = h * P.pair_hist_decay;
+            s_feas[idx] = (P.mask_enable && A.use_mask) ? A.ns.mask[(long long)env * NN + idx] : (ei[t] != ej[t]);
+        }
+        int streak = 0;
+        if (lane < N) {
+            streak = A.ns.streak[(long long)env * N + lane];
+            if (pend > 0) streak = s_part[lane] >= 0 ? 0 : streak + pend;
+        }
+        if (P.qos_enable) {                            // TRAIN:1426-1441 + 858-880
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                if (!ein[t]) continue;
+                const int i = ei[t], j = ej[t];
+                bool okq = false;
+                if (i != j) {
+                    const double pi = s_p[i] * P.P_max, pj = s_p[j] * P.P_max;
+                    const double gi = s_lin[i], gj = s_lin[j];
+                    const bool inear = gi >= gj;
+                    const double gn = inear ? gi : gj, gf = inear ? gj : gi;
+                    const double pn = inear ? pi : pj, pf = inear ? pj : pi;
+                    const double sf = (pf * gf) / (pn * gf + P.noise_power + 1e-12);
+                    const double sn = (pn * gn) / (P.noise_power + 1e-12);
+                    okq = log2(1.0 + fmax(0.0, sf)) >= P.qos_R_min && log2(1.0 + fmax(0.0, sn)) >= P.qos_R_min;
                 }
-            }
-            if (!need_repair && P.freeze_unstick_prob > 0.0) {
-                const double u = A.u_unstick
-                    ? (double)A.u_unstick[env]
-                    : (double)u01(philox4x32_10((uint32_t)(A.ns.env_offset + env), 0u, A.counter, kSiteUnstick, A.seed).x);
-                if (u < P.freeze_unstick_prob) need_repair = true;
+                s_qos[lane + t * kWave] = okq;
             }
         }
+        // ================= solve (TRAIN:1419-1524) ==================================================
+        const int target = max(1, P.min_pair_target);
+        double accept_q = P.mwm_accept_quantile;
+        int K_back = A.K_back;
+        double tau_b = A.tau_back[env];
+        unsigned busy = 0;                             // wave-uniform: users already paired
+        unsigned long long mate = 0;                   // 4 bits per user, valid where busy
         int rounds = 0, npairs = 0, K_last = 0;
-        const bool recompute = !(frozen && !need_repair);
-        if (!recompute) {                              // reuse episode_groups (TRAIN:1542-1547)
-            if (lane < N) s_part[lane] = A.ns.partner[(long long)env * N + lane];
+        while (true) {
+            // ---- score matrix (TRAIN:164-194) ---------------------------------------------------
+            bool any_ok = false;
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                if (!ein[t]) continue;
+                const bool abs_ok = s_g[ei[t]] >= P.abs_gain_min_db || s_g[ej[t]] >= P.abs_gain_min_db;
+                any_ok = any_ok || (s_feas[lane + t * kWave] && abs_ok);
+            }
+            any_ok = __any(any_ok);
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                if (!ein[t]) continue;
+                const int idx = lane + t * kWave, i = ei[t], j = ej[t];
+                const double gap = fabs(s_g[i] - s_g[j]);
+                const bool abs_ok = !any_ok || s_g[i] >= P.abs_gain_min_db || s_g[j] >= P.abs_gain_min_db;
+                const float hterm = P.score_w_history * s_hist[idx];       // float32 product
+                double Sv = P.score_w_delta_db * gap + (double)hterm;
+                if (!(s_feas[idx] && abs_ok)) Sv = -kInf;
+                if (P.qos_enable && !s_qos[idx] && finite(Sv)) Sv = Sv - P.qos_soft_penalty;
+                if (i == j) Sv = -kInf;
+                s_S[idx] = Sv;
+                s_R[idx] = finite(Sv) ? Sv : kInf;     // finite <=> (feasible > 0) & isfinite(S)
+            }
             __syncthreads();
-            for (int v = 0; v < N; ++v) npairs += (s_part[v] >= 0 && s_part[v] < 65536) ? 1 : 0;
-        } else {
-            // ================= solve (TRAIN:1419-1524) ==========================================
-            if (lane < N) {
-                const double g = (double)A.gain[(long long)env * N + lane];
-                s_lin[lane] = g;
-                s_g[lane] = A.gdb12 ? A.gdb12[(long long)env * N + lane] : 10.0 * log10(fmax(g, 1e-12));
-                s_p[lane] = A.p01 ? (double)A.p01[(long long)env * N + lane] : 0.0;
-            }
-            for (int idx = lane; idx < NN; idx += kWave) {
-                const int i = idx / N, j = idx % N;
-                s_feas[idx] = (P.mask_enable && A.use_mask) ? A.ns.mask[(long long)env * NN + idx] : (i != j);
-            }
-            __syncthreads();
-            if (P.qos_enable) {                        // TRAIN:1426-1441 + 858-880
-                for (int idx = lane; idx < NN; idx += kWave) {
-                    const int i = idx / N, j = idx % N;
-                    bool okq = false;
-                    if (i != j) {
-                        const double pi = s_p[i] * P.P_max, pj = s_p[j] * P.P_max;
-                        const double gi = s_lin[i], gj = s_lin[j];
-                        const bool inear = gi >= gj;
-                        const double gn = inear ? gi : gj, gf = inear ? gj : gi;
-                        const double pn = inear ? pi : pj, pf = inear ? pj : pi;
-                        const double sf = (pf * gf) / (pn * gf + P.noise_power + 1e-12);
-                        const double sn = (pn * gn) / (P.noise_power + 1e-12);
-                        okq = log2(1.0 + fmax(0.0, sf)) >= P.qos_R_min && log2(1.0 + fmax(0.0, sn)) >= P.qos_R_min;
-                    }
-                    s_qos[idx] = okq;
-                }
-            }
-            const int target = max(1, P.min_pair_target);
-            double accept_q = P.mwm_accept_quantile;
-            int K_back = A.K_back;
-            double tau_b = A.tau_back[env];
-            unsigned busy = 0;                         // wave-uniform: users already paired
-            unsigned long long mate = 0;               // 4 bits per user, valid where busy
-            while (true) {
-                // ---- score matrix (TRAIN:164-194) -----------------------------------------------
-                bool any_ok = false;
-                for (int idx = lane; idx < NN; idx += kWave) {
-                    const int i = idx / N, j = idx % N;
-                    const bool abs_ok = s_g[i] >= P.abs_gain_min_db || s_g[j] >= P.abs_gain_min_db;
-                    any_ok = any_ok || (s_feas[idx] && abs_ok);
-                }
-                any_ok = __any(any_ok);
-                for (int idx = lane; idx < NN; idx += kWave) {
-                    const int i = idx / N, j = idx % N;
-                    const double gap = fabs(s_g[i] - s_g[j]);
-                    const bool abs_ok = !any_ok || s_g[i] >= P.abs_gain_min_db || s_g[j] >= P.abs_gain_min_db;
-                    const float hterm = P.score_w_history * s_hist[idx];       // float32 product
-                    double S = P.score_w_delta_db * gap + (double)hterm;
-                    if (!(s_feas[idx] && abs_ok)) S = -kInf;
-                    if (P.qos_enable && !s_qos[idx] && finite(S)) S = S - P.qos_soft_penalty;
-                    if (i == j) S = -kInf;
-                    s_S[idx] = S;
-                    s_ok[idx] = finite(S);             // = (feasible > 0) & isfinite(S)
+            Ranks<EPL> R;
+            rank_entries<EPL>(s_R, NN, lane, R);
+            busy = 0; mate = 0; npairs = 0; K_last = 0;
+            if (R.cnt > 0) {
+                // ---- primary matching (TRAIN:326-398) -----------------------------------------------
+                const double q = fmin(fmax(accept_q, 0.0), 1.0);
+                const double thr = quantile_linear<EPL>(R, 1.0 - q);
+#pragma unroll
+                for (int t = 0; t < EPL; ++t) {
+                    if (!ein[t]) continue;
+                    const int idx = lane + t * kWave;
+                    s_W[idx] = (finite(s_S[idx]) && s_S[idx] >= thr) ? s_S[idx] : -kInf;
                 }
                 __syncthreads();
-                Ranks R;
-                rank_entries(s_S, s_ok, NN, lane, R);
-                busy = 0; mate = 0; npairs = 0; K_last = 0;
-                if (R.cnt > 0) {
-                    // ---- primary matching (TRAIN:326-398) -------------------------------------------
-                    const double q = fmin(fmax(accept_q, 0.0), 1.0);
-                    const double thr = quantile_linear(R, 1.0 - q);
-                    for (int idx = lane; idx < NN; idx += kWave)
-                        s_W[idx] = (s_ok[idx] && s_S[idx] >= thr) ? s_S[idx] : -kInf;
-                    __syncthreads();
-                    bool has_edge = false;
-                    if (lane < N)
-                        for (int u = 0; u < N; ++u)
-                            if (u != lane) has_edge = has_edge || finite(s_W[min(lane, u) * N + max(lane, u)]);
-                    unsigned live = (unsigned)__ballot(singles ? has_edge : lane < N) & 0xFFFFu;
-                    const int K = __popc(live);
-                    K_last = K;
-                    if (K > 0) {
-                        // compressed weights w[a][b], a < b (users in increasing order)
-                        for (int idx = lane; idx < K * K; idx += kWave) {
-                            const int a = idx / K, b = idx % K;
-                            unsigned m = live;
-                            int va = 0, vb = 0;
-                            for (int c = 0, pos = 0; m; m &= m - 1, ++c) {
-                                pos = __ffs(m) - 1;
-                                if (c == a) va = pos;
-                                if (c == b) vb = pos;
-                            }
-                            s_w[a * kNV + b] = a < b ? s_W[va * N + vb] : -kInf;
+                bool has_edge = false;
+                if (lane < N)
+                    for (int u = 0; u < N; ++u)
+                        if (u != lane) has_edge = has_edge || finite(s_W[min(lane, u) * N + max(lane, u)]);
+                const unsigned live = (unsigned)__ballot(singles ? has_edge : lane < N) & 0xFFFFu;
+                const int K = __popc(live);
+                K_last = K;
+                if (K > 0) {
+                    // compressed weights w[a][b], a < b (users in increasing order); table layout
+                    for (int idx = lane; idx < K * K; idx += kWave) {
+                        const int a = idx / K, b = idx % K;
+                        unsigned m = live;
+                        int va = 0, vb = 0;
+                        for (int c = 0; m; m &= m - 1, ++c) {
+                            const int pos = __ffs(m) - 1;
+                            if (c == a) va = pos;
+                            if (c == b) vb = pos;
                         }
-                        const int full = (1 << K) - 1;
-                        double* T = s_dp;
-                        if (K > KL) T = A.ns.scratch + ((size_t)blockIdx.x << N);
-                        if (lane == 0) T[full] = 0.0;
-                        for (int pc = K - 1; pc >= 0; --pc) {
-                            __syncthreads();
-                            for (int m = lane; m < full; m += kWave) {
-                                if (__popc(m) != pc) continue;
-                                int arg;
-                                const double b = best_at(T, s_w, K, singles, m, arg);
-                                T[m] = arg == -2 ? 0.0 : b;        // TRAIN:389-390
-                            }
+                        s_w[a * kNV + b] = a < b ? s_W[va * N + vb] : -kInf;
+                    }
+                    if (lane == 0) {
+                        int off = 0;
+                        for (int x = 0; x < K; ++x) {
+                            s_base[x] = off;
+                            const int n = K - 1 - x;
+                            off += s_sizeoff[n * (kBinW + 1) + min(x, n) + 1];
+                        }
+                        s_base[K] = off;
+                    }
+                    __syncthreads();
+                    const MatchTab MT{s_dp, s_base, s_binom, s_sizeoff, K, (1 << K) - 1, K <= S::KPLAIN};
+                    for (int x = K - 1; x >= 0; --x) {          // a state only needs states with a larger x
+                        const int n = K - 1 - x, low = (1 << x) - 1;
+                        for (int T = lane; T < (1 << n); T += kWave) {
+                            if (__popc(T) > x) continue;         // not reachable
+                            const int m = low | (T << (x + 1));
+                            int arg;
+                            const double b = best_at(MT, s_w, singles, m, arg);
+                            const int sl = MT.slot(m);
+                            s_dp[sl] = arg == -2 ? 0.0 : b;            // TRAIN:389-390
+                            s_arg[sl] = (signed char)arg;
                         }
                         __syncthreads();
-                        // walk the choices from the empty mask (every lane, same reads)
-                        int m = 0;
-                        while (m != full) {
-                            int arg;
-                            best_at(T, s_w, K, singles, m, arg);
-                            if (arg == -2) break;
-                            const int x = __ffs(~m) - 1;
-                            m |= 1 << x;
-                            if (arg >= 0) {
-                                m |= 1 << arg;
-                                unsigned lm = live;
-                                int vx = 0, vj = 0;
-                                for (int c = 0; lm; lm &= lm - 1, ++c) {
-                                    const int pos = __ffs(lm) - 1;
-                                    if (c == x) vx = pos;
-                                    if (c == arg) vj = pos;
-                                }
-                                busy |= (1u << vx) | (1u << vj);
-                                mate |= ((unsigned long long)vj << (4 * vx)) | ((unsigned long long)vx << (4 * vj));
-                                ++npairs;
-                            }
-                        }
                     }
-                    // ---- greedy completion (TRAIN:276-324) ------------------------------------------
-                    if (npairs < target) {
-                        const double thr2 = quantile_linear(R, P.completion_min_quantile);
-                        while (npairs < target) {
-                            double bs = -kInf;
-                            int bi = -1;
-                            for (int idx = lane; idx < NN; idx += kWave) {
-                                const int i = idx / N, j = idx % N;
-                                if (i < j && s_ok[idx] && s_S[idx] >= thr2 && !((busy >> i) & 1) && !((busy >> j) & 1)) {
-                                    const double s = s_S[idx];
-                                    if (bi < 0 || s > bs || (s == bs && idx > bi)) { bs = s; bi = idx; }
-                                }
+                    // walk the choices from the empty mask (every lane, same reads)
+                    int m = 0;
+                    while (m != MT.full) {
+                        const int arg = s_arg[MT.slot(m)];
+                        if (arg == -2) break;
+                        const int x = __ffs(~m) - 1;
+                        m |= 1 << x;
+                        if (arg >= 0) {
+                            m |= 1 << arg;
+                            unsigned lm = live;
+                            int vx = 0, vj = 0;
+                            for (int c = 0; lm; lm &= lm - 1, ++c) {
+                                const int pos = __ffs(lm) - 1;
+                                if (c == x) vx = pos;
+                                if (c == arg) vj = pos;
                             }
-#pragma unroll
-                            for (int o = kWave / 2; o > 0; o >>= 1) {
-                                const double os = __shfl_xor(bs, o, kWave);
-                                const int oi = __shfl_xor(bi, o, kWave);
-                                if (oi >= 0 && (bi < 0 || os > bs || (os == bs && oi > bi))) { bs = os; bi = oi; }
-                            }
-                            if (bi < 0) break;
-                            const int i = bi / N, j = bi % N;
-                            busy |= (1u << i) | (1u << j);
-                            mate |= ((unsigned long long)j << (4 * i)) | ((unsigned long long)i << (4 * j));
+                            busy |= (1u << vx) | (1u << vj);
+                            mate |= ((unsigned long long)vj << (4 * vx)) | ((unsigned long long)vx << (4 * vj));
                             ++npairs;
                         }
                     }
                 }
-                // ---- back-off (TRAIN:1493-1524) -----------------------------------------------------
-                if (npairs >= target || rounds >= P.mwm_backoff_rounds) break;
-                ++rounds;
-                K_back = min(N - 1, K_back + P.relax_topk_step);
-                tau_b = fmax(P.tau_back_floor_db, tau_b * P.relax_tau_factor);
-                __syncthreads();
-                for (int idx = lane; idx < NN; idx += kWave) {     // _relax_mask_once, TRAIN:260-275
-                    const int i = idx / N, j = idx % N;
-                    const double gap = fabs(s_g[i] - s_g[j]);
-                    int rank = 0;                                   // position in argsort(-gap[i]), equal keys by index
-                    for (int k = 0; k < N; ++k) {
-                        const double gk = fabs(s_g[i] - s_g[k]);
-                        rank += (gk > gap || (gk == gap && k < j)) ? 1 : 0;
+                // ---- greedy completion (TRAIN:276-324) ----------------------------------------------
+                if (npairs < target) {
+                    const double thr2 = quantile_linear<EPL>(R, P.completion_min_quantile);
+                    while (npairs < target) {
+                        double bs = -kInf;
+                        int bi = -1;
+#pragma unroll
+                        for (int t = 0; t < EPL; ++t) {
+                            if (!ein[t]) continue;
+                            const int idx = lane + t * kWave, i = ei[t], j = ej[t];
+                            const double s = s_S[idx];
+                            if (i < j && finite(s) && s >= thr2 && !((busy >> i) & 1) && !((busy >> j) & 1))
+                                if (bi < 0 || s > bs || (s == bs && idx > bi)) { bs = s; bi = idx; }
+                        }
+#pragma unroll
+                        for (int o = kWave / 2; o > 0; o >>= 1) {
+                            const double os = __shfl_xor(bs, o, kWave);
+                            const int oi = __shfl_xor(bi, o, kWave);
+                            if (oi >= 0 && (bi < 0 || os > bs || (os == bs && oi > bi))) { bs = os; bi = oi; }
+                        }
+                        if (bi < 0) break;
+                        const int i = bi / N, j = bi % N;
+                        busy |= (1u << i) | (1u << j);
+                        mate |= ((unsigned long long)j << (4 * i)) | ((unsigned long long)i << (4 * j));
+                        ++npairs;
                     }
-                    const bool top = K_back >= 1 && rank < min(K_back, N - 1);
-                    const bool cand = gap >= tau_b && i != j;
-                    s_feas[idx] = (s_feas[idx] || cand || top) ? 1 : 0;
                 }
-                accept_q = fmax(0.05, accept_q - P.mwm_accept_q_step);
-                __syncthreads();
             }
-            if (lane < N) {                            // episode_groups <- pairs + singles (TRAIN:1548-1553)
-                int p = -1;
-                if ((busy >> lane) & 1) {
-                    const int m = (int)((mate >> (4 * lane)) & 15);
-                    p = m > lane ? m : m + 65536;      // pairs are listed (low, high)
+            // ---- back-off (TRAIN:1493-1524) ---------------------------------------------------------
+            if (npairs >= target || rounds >= P.mwm_backoff_rounds) break;
+            ++rounds;
+            K_back = min(N - 1, K_back + P.relax_topk_step);
+            tau_b = fmax(P.tau_back_floor_db, tau_b * P.relax_tau_factor);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {                     // _relax_mask_once, TRAIN:260-275
+                if (!ein[t]) continue;
+                const int idx = lane + t * kWave, i = ei[t], j = ej[t];
+                const double gap = fabs(s_g[i] - s_g[j]);
+                int rank = 0;                                   // position in argsort(-gap[i]), equal keys by index
+                for (int k = 0; k < N; ++k) {
+                    const double gk = fabs(s_g[i] - s_g[k]);
+                    rank += (gk > gap || (gk == gap && k < j)) ? 1 : 0;
                 }
-                s_part[lane] = p;
-                A.ns.partner[(long long)env * N + lane] = p;
+                const bool top = K_back >= 1 && rank < min(K_back, N - 1);
+                const bool cand = gap >= tau_b && i != j;
+                s_feas[idx] = (s_feas[idx] || cand || top) ? 1 : 0;
             }
-            flags |= RISVEC_NOMA_HAS_GROUPS;
+            accept_q = fmax(0.05, accept_q - P.mwm_accept_q_step);
             __syncthreads();
         }
-        // ---- history / streak update (TRAIN:1556-1561), outputs --------------------------------------
-        for (int idx = lane; idx < NN; idx += kWave) {
-            const int i = idx / N, j = idx % N;
-            const int p = s_part[i];
+        __syncthreads();
+        // ---- episode_groups <- pairs + singles (TRAIN:1548-1553); history / streak (TRAIN:1556-1561) -----
+        if (lane < N) {
+            int p = -1;
+            if ((busy >> lane) & 1) {
+                const int m = (int)((mate >> (4 * lane)) & 15);
+                p = m > lane ? m : m + 65536;          // pairs are listed (low, high)
+            }
+            s_part[lane] = p;
+            A.ns.partner[(long long)env * N + lane] = p;
+            A.ns.streak[(long long)env * N + lane] = p >= 0 ? 0 : streak + 1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            if (!ein[t]) continue;
+            const int idx = lane + t * kWave;
             float h = s_hist[idx];
-            if (p >= 0 && (p & 0xFFFF) == j) h += 1.0f;
+            if (paired_with(s_part[ei[t]], ej[t])) h += 1.0f;
             hist[idx] = h;
         }
-        if (lane < N) {
-            const int p = s_part[lane];
-            int* st = A.ns.streak + (long long)env * N + lane;
-            *st = p >= 0 ? 0 : *st + 1;
-            A.partner_out[(long long)env * N + lane] = p;
-        }
         if (lane == 0) {
-            const int ng = N - npairs;
-            if (recompute) A.ns.n_groups[env] = ng;
-            A.n_groups_out[env] = ng;
-            A.ns.flags[env] = (uint8_t)flags;
-            A.ns.last_global[env] = last;
-            A.ns.best_global[env] = best;
+            A.ns.n_groups[env] = N - npairs;
+            A.ns.flags[env] = (uint8_t)(flags | RISVEC_NOMA_HAS_GROUPS);
+            A.ns.pending[env] = 0;
             if (A.info_out) {
                 int* o = A.info_out + (long long)env * 4;
-                o[0] = recompute ? 1 : 0; o[1] = rounds; o[2] = npairs; o[3] = K_last;
+                o[0] = 1; o[1] = rounds; o[2] = npairs; o[3] = K_last;
             }
+        }
+    }
+    }   // blockIdx.x < n_todo
+    // every block has read the list length by the time it gets here: the last one to leave clears
+    // it for the next call (saves a memset launch on the frozen steps, which are launch-bound)
+    if (lane == 0) {
+        int* ctl = A.ns.todo + A.ns.n_envs;
+        __threadfence();
+        if (atomicAdd(ctl + 1, 1) == (int)gridDim.x - 1) {
+            ctl[0] = 0;
+            ctl[1] = 0;
         }
     }
 }
 
 // tau = quantile q of |g_strong - g_weak| (TRAIN:842-855) and the feasibility mask (TRAIN:134-156).
+template <int NMAX>
 __global__ void __launch_bounds__(kWave)
 k_noma_mask(RisVecNomaState ns, const float* gain, const double* gdb15, double q_now, int K_now) {
-    __shared__ double s_g[kNV], s_d[kNN];
-    __shared__ uint8_t s_ok[kNN], s_m[kNN], s_keep[kNN];
+    constexpr int NNM = NMAX * NMAX, EPL = NNM / kWave;
+    __shared__ double s_g[kNV], s_d[NNM], s_R[NNM];
+    __shared__ uint8_t s_m[NNM], s_keep[NNM];
     const int lane = threadIdx.x;
     const int N = ns.n_veh, NN = N * N;
     for (int env = blockIdx.x; env < ns.n_envs; env += gridDim.x) {
@@ -428,15 +582,16 @@ k_noma_mask(RisVecNomaState ns, const float* gain, const double* gdb15, double q
                 ri += (s_g[k] < s_g[i] || (s_g[k] == s_g[i] && k < i)) ? 1 : 0;
                 rj += (s_g[k] < s_g[j] || (s_g[k] == s_g[j] && k < j)) ? 1 : 0;
             }
-            s_ok[idx] = ri >= N / 2 && rj < N / 2;          // i strong, j weak
-            s_d[idx] = fabs(s_g[i] - s_g[j]);
+            const double dgap = fabs(s_g[i] - s_g[j]);
+            s_d[idx] = dgap;
+            s_R[idx] = (ri >= N / 2 && rj < N / 2) ? dgap : kInf;     // i strong, j weak
         }
         __syncthreads();
         double tau = 0.0;
         if (N >= 2) {
-            Ranks R;
-            rank_entries(s_d, s_ok, NN, lane, R);
-            tau = quantile_linear(R, q_now);
+            Ranks<EPL> R;
+            rank_entries<EPL>(s_R, NN, lane, R);
+            tau = quantile_linear<EPL>(R, q_now);
         }
         if (lane == 0) ns.tau[env] = tau;
         if (K_now < 1) continue;
@@ -464,7 +619,7 @@ k_noma_mask(RisVecNomaState ns, const float* gain, const double* gdb15, double q
     }
 }
 
-int noma_grid(int E, int cap) {
+int noma_grid(int E) {
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 256;
@@ -472,8 +627,7 @@ int noma_grid(int E, int cap) {
         return n;
     }();
     const int want = cus * 16;
-    int g = E < want ? E : want;
-    if (cap > 0 && g > cap) g = cap;
+    const int g = E < want ? E : want;
     return g < 1 ? 1 : g;
 }
 
@@ -485,29 +639,47 @@ hipError_t launch_noma_begin_episode(const RisVecNomaState& ns, hipStream_t st) 
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(ns.streak, 0, E * N * sizeof(int32_t), st);
     if (err != hipSuccess) return err;
+    err = hipMemsetAsync(ns.pending, 0, E * sizeof(int32_t), st);
+    if (err != hipSuccess) return err;
     return hipMemsetAsync(ns.flags, 0, E, st);
 }
 
 hipError_t launch_noma_mask(const RisVecNomaState& ns, const float* gain, const double* gdb15, double q_now,
                             int K_now, hipStream_t st) {
-    hipLaunchKernelGGL(k_noma_mask, dim3(noma_grid(ns.n_envs, 0)), dim3(kWave), 0, st, ns, gain, gdb15, q_now, K_now);
+    const dim3 grid(noma_grid(ns.n_envs));
+    if (ns.n_veh <= 8) hipLaunchKernelGGL(k_noma_mask<8>, grid, dim3(kWave), 0, st, ns, gain, gdb15, q_now, K_now);
+    else hipLaunchKernelGGL(k_noma_mask<16>, grid, dim3(kWave), 0, st, ns, gain, gdb15, q_now, K_now);
     return hipGetLastError();
 }
 
-// slots: how many envs may use the HBM spill of the matching table at once (0 = none available)
+hipError_t launch_noma_flush(const RisVecNomaState& ns, float decay, hipStream_t st) {
+    const long long n = (long long)ns.n_envs * ns.n_veh * ns.n_veh;
+    hipLaunchKernelGGL(k_noma_flush, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, ns, decay);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_noma_clear_pending, dim3((ns.n_envs + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ns);
+    return hipGetLastError();
+}
+
 hipError_t launch_noma_group(const RisVecNomaState& ns, const RisVecNomaParams& p, const float* gain,
-                             const double* gdb12, const float* p01, int use_mask, double q_back, int K_back,
+                             const double* gdb12, const float* p01, int use_mask, int K_back,
                              const double* tau_back, const float* prev_global, int prev_stride, int i_step,
-                             const float* u_unstick, uint64_t seed, uint32_t counter, int32_t* partner_out,
-                             int32_t* n_groups_out, int32_t* info_out, int slots, hipStream_t st) {
-    NomaArgs a{ns, p, gain, gdb12, p01, use_mask, q_back, K_back, tau_back, prev_global, prev_stride, i_step,
-               u_unstick, seed, counter, partner_out, n_groups_out, info_out};
-    if (ns.n_veh <= 8) {
-        hipLaunchKernelGGL((k_noma_group<8>), dim3(noma_grid(ns.n_envs, 0)), dim3(kWave), 0, st, a);
-    } else {
-        const int cap = ns.n_veh > 12 ? slots : 0;     // every resident env needs its own spill slot
-        hipLaunchKernelGGL((k_noma_group<12>), dim3(noma_grid(ns.n_envs, cap)), dim3(kWave), 0, st, a);
-    }
+                             const float* u_unstick, uint64_t seed, uint32_t counter, int32_t* info_out,
+                             hipStream_t st) {
+    NomaArgs a{ns, p, gain, gdb12, p01, use_mask, K_back, tau_back, prev_global, prev_stride, i_step,
+               u_unstick, seed, counter, info_out};
+    hipLaunchKernelGGL(k_noma_pre, dim3((ns.n_envs + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    // The list length is only known on the device: a fixed grid walks it (blocks beyond it exit at
+    // once).  Steps on which most envs are expected to be frozen get a small grid -- an empty 4 096-block
+    // launch costs more than the whole frozen step otherwise; a wrong guess only costs speed.
+    const bool busy_step = !p.freeze_group_in_episode || i_step <= 1 ||
+                           (p.freeze_recalc_every > 0 && i_step % p.freeze_recalc_every == 0);
+    int grid = noma_grid(ns.n_envs);
+    if (!busy_step && grid > 128) grid = 128;
+    if (ns.n_veh <= 8) hipLaunchKernelGGL((k_noma_solve<8>), dim3(grid), dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL((k_noma_solve<16>), dim3(grid), dim3(kWave), 0, st, a);
     return hipGetLastError();
 }
 

@@ -335,6 +335,7 @@ int risvec_noma_begin_episode(const RisVecNomaState* ns, risvec_stream_t stream)
     const char* fn = "risvec_noma_begin_episode";
     if (int rc = check_noma(fn, ns)) return rc;
     REQ_PTR(ns->hist, "noma.hist"); REQ_PTR(ns->streak, "noma.streak"); REQ_PTR(ns->flags, "noma.flags");
+    REQ_PTR(ns->pending, "noma.pending");
     return finish(fn, risvec::launch_noma_begin_episode(*ns, (hipStream_t)stream));
 }
 
@@ -350,20 +351,24 @@ int risvec_noma_mask(const RisVecNomaState* ns, const float* gain, const double*
     return finish(fn, risvec::launch_noma_mask(*ns, gain, gdb15, q_now, K_now, (hipStream_t)stream));
 }
 
+static int check_noma_state(const char* fn, const RisVecNomaState* ns) {
+    REQ_PTR(ns->hist, "noma.hist"); REQ_PTR(ns->streak, "noma.streak"); REQ_PTR(ns->partner, "noma.partner");
+    REQ_PTR(ns->n_groups, "noma.n_groups"); REQ_PTR(ns->last_global, "noma.last_global");
+    REQ_PTR(ns->best_global, "noma.best_global"); REQ_PTR(ns->flags, "noma.flags");
+    REQ_PTR(ns->pending, "noma.pending"); REQ_PTR(ns->todo, "noma.todo");
+    return RISVEC_OK;
+}
+
 int risvec_noma_group(const RisVecNomaState* ns, const RisVecNomaParams* np, const float* gain, const double* gdb12,
-                      const float* p_off01, int32_t use_mask, double q_back, int32_t K_back, const double* tau_back,
+                      const float* p_off01, int32_t use_mask, int32_t K_back, const double* tau_back,
                       const float* prev_global, int32_t prev_global_stride, int32_t i_step, const float* u_unstick,
-                      uint64_t seed, uint32_t counter, int32_t* partner_out, int32_t* n_groups_out, int32_t* info_out,
-                      risvec_stream_t stream) {
+                      uint64_t seed, uint32_t counter, int32_t* info_out, risvec_stream_t stream) {
     const char* fn = "risvec_noma_group";
     if (int rc = check_noma(fn, ns)) return rc;
     if (!np) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     REQ_PTR(gain, "gain"); OPT_PTR(gdb12, "gdb12"); OPT_PTR(p_off01, "p_off01"); REQ_PTR(tau_back, "tau_back");
-    OPT_PTR(u_unstick, "u_unstick"); REQ_PTR(partner_out, "partner_out"); REQ_PTR(n_groups_out, "n_groups_out");
-    OPT_PTR(info_out, "info_out");
-    REQ_PTR(ns->hist, "noma.hist"); REQ_PTR(ns->streak, "noma.streak"); REQ_PTR(ns->partner, "noma.partner");
-    REQ_PTR(ns->n_groups, "noma.n_groups"); REQ_PTR(ns->last_global, "noma.last_global");
-    REQ_PTR(ns->best_global, "noma.best_global"); REQ_PTR(ns->flags, "noma.flags");
+    OPT_PTR(u_unstick, "u_unstick"); OPT_PTR(info_out, "info_out");
+    if (int rc = check_noma_state(fn, ns)) return rc;
     if (np->qos_enable && !p_off01) return fail(RISVEC_ERR_ARG, "%s: qos_enable needs p_off01", fn);
     if (np->mask_enable && use_mask) REQ_PTR(ns->mask, "noma.mask");
     if (prev_global && prev_global_stride < 1)
@@ -373,19 +378,17 @@ int risvec_noma_group(const RisVecNomaState* ns, const RisVecNomaParams* np, con
     if (K_back < 0) return fail(RISVEC_ERR_ARG, "%s: K_back=%d must be >= 0", fn, K_back);
     if (np->mwm_backoff_rounds < 0 || np->mwm_backoff_rounds > 64)
         return fail(RISVEC_ERR_ARG, "%s: mwm_backoff_rounds=%d outside [0,64]", fn, np->mwm_backoff_rounds);
-    int slots = 0;
-    if (ns->n_veh > 12) {       // the matching table of > 12 matchable users does not fit LDS
-        const uint64_t per_env = 8ull << ns->n_veh;
-        if (!ns->scratch || ns->scratch_bytes < per_env)
-            return fail(RISVEC_ERR_ARG, "%s: n_veh=%d needs noma.scratch of at least %llu bytes", fn, ns->n_veh,
-                        (unsigned long long)per_env);
-        REQ_PTR(ns->scratch, "noma.scratch");
-        const uint64_t fit = ns->scratch_bytes / per_env;
-        slots = (int)(fit > 1024 ? 1024 : fit);
-    }
-    return finish(fn, risvec::launch_noma_group(*ns, *np, gain, gdb12, p_off01, use_mask, q_back, K_back, tau_back,
+    return finish(fn, risvec::launch_noma_group(*ns, *np, gain, gdb12, p_off01, use_mask, K_back, tau_back,
                                                 prev_global, prev_global_stride, i_step, u_unstick, seed, counter,
-                                                partner_out, n_groups_out, info_out, slots, (hipStream_t)stream));
+                                                info_out, (hipStream_t)stream));
+}
+
+int risvec_noma_flush(const RisVecNomaState* ns, const RisVecNomaParams* np, risvec_stream_t stream) {
+    const char* fn = "risvec_noma_flush";
+    if (int rc = check_noma(fn, ns)) return rc;
+    if (!np) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_noma_state(fn, ns)) return rc;
+    return finish(fn, risvec::launch_noma_flush(*ns, np->pair_hist_decay, (hipStream_t)stream));
 }
 
 }  // extern "C"

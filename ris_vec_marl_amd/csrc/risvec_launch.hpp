@@ -46,10 +46,11 @@ hipError_t launch_noma_begin_episode(const RisVecNomaState& ns, hipStream_t st);
 hipError_t launch_noma_mask(const RisVecNomaState& ns, const float* gain, const double* gdb15, double q_now,
                             int K_now, hipStream_t st);
 hipError_t launch_noma_group(const RisVecNomaState& ns, const RisVecNomaParams& p, const float* gain,
-                             const double* gdb12, const float* p01, int use_mask, double q_back, int K_back,
+                             const double* gdb12, const float* p01, int use_mask, int K_back,
                              const double* tau_back, const float* prev_global, int prev_stride, int i_step,
-                             const float* u_unstick, uint64_t seed, uint32_t counter, int32_t* partner_out,
-                             int32_t* n_groups_out, int32_t* info_out, int slots, hipStream_t st);
+                             const float* u_unstick, uint64_t seed, uint32_t counter, int32_t* info_out,
+                             hipStream_t st);
+hipError_t launch_noma_flush(const RisVecNomaState& ns, float decay, hipStream_t st);
 
 inline Dims dims_of(const RisVecState& s) {
     return Dims{s.n_envs, s.n_veh, s.n_ris, s.control_bit, (long long)s.env_offset};

@@ -148,8 +148,6 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 class NomaGrouper:
     """Episode-scoped pairing state of TRAIN:1282-1300 for E envs + the three driver moments."""
 
-    SPILL_SLOTS = 1024       # concurrently resident envs that may spill their matching table (n_veh > 12)
-
     def __init__(self, env, config: Optional[NomaConfig] = None):
         self.env = env
         self.n_envs, self.n_veh = int(env.n_envs), int(env.n_veh)
@@ -186,19 +184,14 @@ class NomaGrouper:
         t["flags"] = z(E, dt=torch.uint8)
         t["mask"] = z(E, V, V, dt=torch.uint8)
         t["tau"] = z(E, dt=torch.float64)
-        t["partner_out"] = z(E, V, dt=torch.int32)
-        t["n_groups_out"] = z(E, dt=torch.int32)
+        t["pending"] = z(E, dt=torch.int32)
+        t["todo"] = z(E + 4, dt=torch.int32)
         t["info"] = z(E, 4, dt=torch.int32)
         s = N.RisVecNomaState()
         s.n_envs, s.n_veh, s.env_offset = E, V, int(getattr(self.env, "env_offset", 0))
-        for k in ("hist", "streak", "partner", "n_groups", "last_global", "best_global", "flags", "mask", "tau"):
+        for k in ("hist", "streak", "partner", "n_groups", "last_global", "best_global", "flags", "mask", "tau",
+                  "pending", "todo"):
             setattr(s, k, t[k].data_ptr())
-        if V > 12:
-            slots = min(self.SPILL_SLOTS, E)
-            t["scratch"] = z(slots << V, dt=torch.float64)
-            s.scratch, s.scratch_bytes = t["scratch"].data_ptr(), t["scratch"].numel() * 8
-        else:
-            s.scratch, s.scratch_bytes = None, 0
         self._cstate = s
 
     def _stream(self) -> int:
@@ -238,7 +231,7 @@ class NomaGrouper:
               gdb15: Optional[torch.Tensor] = None, u_unstick: Optional[torch.Tensor] = None
               ) -> Tuple[torch.Tensor, torch.Tensor]:
         """TRAIN:1401-1562 for every env -> (partner [E,N] int32, n_groups [E] int32), the batched
-        `noma_groups` `VecEnviron.step` takes.  `p_off01` [E,N] is the offload power in [0,1] the
+        `noma_groups` `VecEnviron.step` takes (views of the grouper's state, valid until the next call).  `p_off01` [E,N] is the offload power in [0,1] the
         policy chose (TRAIN:1391-1396).  `prev_global` defaults to the global reward the env's last
         `step` left in `metrics[:,0]` (none before the first step of the episode).  `gdb12` / `gdb15`
         inject a host's float64 dB gains (parity interface); `u_unstick` injects the TRAIN:1539 draw."""
@@ -254,7 +247,7 @@ class NomaGrouper:
             if prev_global.dtype != torch.float32 or prev_global.device != self.device:
                 raise ValueError("prev_global must be a float32 tensor on %s" % self.device)
         if cfg.mask_enable and self._have_mask:                        # TRAIN:1486-1491
-            q_back, K_back, tau_back = self._q_now, self._K_now, t["tau"]
+            K_back, tau_back = self._K_now, t["tau"]
         else:
             q_back = float(cfg.pairing_threshold_quantile)
             K_back = anneal_topk(self.i_episode, self.n_veh, cfg.mask_topk_start, cfg.mask_topk_end,
@@ -271,12 +264,55 @@ class NomaGrouper:
         self._calls += 1
         N.check(N.load().risvec_noma_group(
             C.byref(self._cstate), C.byref(self._params()), _ptr(g), _ptr(self._f64(gdb12)), _ptr(p01),
-            1 if (cfg.mask_enable and self._mask_fresh) else 0, float(q_back), int(K_back), _ptr(tau_back),
+            1 if (cfg.mask_enable and self._mask_fresh) else 0, int(K_back), _ptr(tau_back),
             _ptr(prev_global), int(stride), int(i_step), _ptr(uu), int(getattr(self.env, "seed", 0)),
-            self._calls, _ptr(t["partner_out"]), _ptr(t["n_groups_out"]), _ptr(t["info"]), self._stream()))
+            self._calls, _ptr(t["info"]), self._stream()))
         self._mask_fresh = False
         self._have_reward = True        # the caller steps the env next; its metrics[:,0] feeds the next call
-        return t["partner_out"], t["n_groups_out"]
+        return t["partner"], t["n_groups"]
+
+    def bind_group(self, p_off01: Optional[torch.Tensor]):
+        """`group()` with everything that does not change from step to step validated and
+        marshalled once: returns `launch(i_step)`, one pre-built C-ABI call per step (the frozen
+        steps of an episode are launch-bound, so host time matters).  Inputs are read in place:
+        `p_off01` (updated by the caller between steps), the env's `gain` and the global reward
+        its last `step` left in `metrics[:,0]`; `info` is not refreshed on this path.  Valid for the current episode's mask state and
+        config; `begin_episode` / `refresh_mask` / config changes need a new binding only if
+        `mask_enable` is off (tau is then recomputed per call by `group()`, not here)."""
+        self._ensure_device()
+        cfg, t = self.config, self._t
+        if not cfg.mask_enable:
+            raise ValueError("bind_group needs mask_enable (the cached tau / K of the last refresh_mask)")
+        p01 = None
+        if p_off01 is not None:
+            if (p_off01.dtype != torch.float32 or p_off01.device != self.device or not p_off01.is_contiguous()
+                    or tuple(p_off01.shape) != (self.n_envs, self.n_veh)):
+                raise ValueError("p_off01 must be a contiguous float32 [n_envs, n_veh] tensor on %s" % self.device)
+            p01 = p_off01
+        lib, cs, prm = N.load(), C.byref(self._cstate), self._params()
+        fn, check = lib.risvec_noma_group, N.check
+        g, metrics = self.env._t["gain"], self.env._t["metrics"]
+        gp, pp, tp, mp, ip = g.data_ptr(), _ptr(p01), t["tau"].data_ptr(), metrics.data_ptr(), t["info"].data_ptr()
+        stride, seed, stream = int(metrics.stride(0)), int(getattr(self.env, "seed", 0)), self._stream()
+        pref = C.byref(prm)
+
+        def launch(i_step: int) -> None:
+            if not self._have_mask:
+                raise RuntimeError("bind_group: call refresh_mask() first in each episode")
+            self._calls += 1
+            check(fn(cs, pref, gp, None, pp, 1 if self._mask_fresh else 0, self._K_now, tp,
+                     mp if self._have_reward else None, stride, i_step, None, seed, self._calls, None, stream))
+            self._mask_fresh = False
+            self._have_reward = True
+
+        launch.keepalive = (prm, p01, g, metrics)
+        return launch
+
+    def flush(self) -> None:
+        """Apply the frozen steps still owed to `pair_affinity_hist` / `unpaired_streak` (the kernels
+        defer that bookkeeping and replay it operation for operation when it is next needed)."""
+        self._ensure_device()
+        N.check(N.load().risvec_noma_flush(C.byref(self._cstate), C.byref(self._params()), self._stream()))
 
     # ------------------------------------------------------------------ views
     def _gain(self, gain):
@@ -303,10 +339,12 @@ class NomaGrouper:
 
     @property
     def pair_affinity_hist(self) -> torch.Tensor:
+        self.flush()
         return self._t["hist"]
 
     @property
     def unpaired_streak(self) -> torch.Tensor:
+        self.flush()
         return self._t["streak"]
 
     @property

@@ -84,8 +84,11 @@ def test_mask_kernel_vs_golden(path):
             assert np.array_equal(mask.cpu().numpy()[0], d["mask"][c].astype(np.uint8)), c
 
 
+@pytest.mark.parametrize("lazy", [False, True], ids=["flush-every-step", "deferred"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "noma_episodes_*.npz"))), ids=os.path.basename)
-def test_episodes_vs_golden_and_oracle(path):
+def test_episodes_vs_golden_and_oracle(path, lazy):
+    """lazy=True reads the history / streak tensors only at the end of each episode, so frozen steps
+    accumulate in `pending` and are replayed inside the solve kernel (or by the final flush)."""
     from ris_vec_marl_amd import NomaGrouper
     d = np.load(path)
     N = int(d["N"])
@@ -128,8 +131,10 @@ def test_episodes_vs_golden_and_oracle(path):
             assert bool(dinfo[0]) == info["recomputed"] and dinfo[2] == info["n_pairs"]
             if info["recomputed"]:
                 assert dinfo[1] == info["rounds"]
-            assert np.array_equal(grouper.pair_affinity_hist.cpu().numpy()[0], ep.hist)
-            assert np.array_equal(grouper.unpaired_streak.cpu().numpy()[0], ep.streak)
+            look = (not lazy) or t == n_steps - 1
+            if look:
+                assert np.array_equal(grouper.pair_affinity_hist.cpu().numpy()[0], ep.hist)
+                assert np.array_equal(grouper.unpaired_streak.cpu().numpy()[0], ep.streak)
             fl = int(grouper.flags.cpu().numpy()[0])
             assert bool(fl & 2) == ep.unstick_used and bool(fl & 4) == (ep.groups is not None)
             # ---- device vs golden: wherever the reference's sort ties cannot reach ----------------------
@@ -139,8 +144,9 @@ def test_episodes_vs_golden_and_oracle(path):
             if gold_ok:
                 assert np.array_equal(partner, d["partner"][e, t]), (e, t)
                 assert ng == d["n_groups"][e, t]
-                assert np.array_equal(grouper.pair_affinity_hist.cpu().numpy()[0], d["hist"][e, t])
-                assert np.array_equal(grouper.unpaired_streak.cpu().numpy()[0], d["streak"][e, t])
+                if look:
+                    assert np.array_equal(grouper.pair_affinity_hist.cpu().numpy()[0], d["hist"][e, t])
+                    assert np.array_equal(grouper.unpaired_streak.cpu().numpy()[0], d["streak"][e, t])
                 checked_gold += 1
     assert checked_gold > 0.6 * n_ep * n_steps, checked_gold
 
@@ -200,9 +206,9 @@ def test_batched_device_log10_vs_oracle(N, yaml):
     assert max_ulp <= 1.0, max_ulp
 
 
-def test_dense_matching_spills_to_hbm():
-    """16 users, every feasible edge admitted (accept quantile 1): up to 16 matchable users -> the
-    2^16-entry table lives in the HBM scratch slot.  Exact against the oracle."""
+def test_dense_matching_16_users():
+    """16 users, every feasible edge admitted (accept quantile 1): all 16 users matchable -> the full
+    2 583-state reachable table.  Exact against the oracle's plain 2^16 bottom-up table."""
     from ris_vec_marl_amd import NomaGrouper
     N, E = 16, 6
     rng = np.random.default_rng(7)
@@ -215,7 +221,7 @@ def test_dense_matching_spills_to_hbm():
     gdb12 = NO.gain_db(g.astype(np.float64), 1e-12)
     partner, ng = grouper.group(None, 0, gain=T(g), gdb12=T(gdb12), gdb15=T(gdb15))
     partner = partner.cpu().numpy()
-    assert int(grouper.info.cpu().numpy()[:, 3].max()) > 12        # the spill path really ran
+    assert int(grouper.info.cpu().numpy()[:, 3].max()) == 16
     for e in range(E):
         ep = NO.NomaEpisode(N)
         groups, _ = NO.group_step(ep, g[e].astype(np.float64), np.zeros(N), None, prm, 0, 0, gdb15=gdb15[e],
