@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 5
+#define RISVEC_ABI_VERSION 6
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -378,6 +378,49 @@ int risvec_noma_group(const RisVecNomaState *ns, const RisVecNomaParams *np, con
 
 /* Apply the deferred frozen steps to hist / streak (pair_hist_decay = np->pair_hist_decay). */
 int risvec_noma_flush(const RisVecNomaState *ns, const RisVecNomaParams *np, risvec_stream_t stream);
+
+/* ===========================================================================================
+ * Replay ring buffer + policy-output marshalling: buffer.py (BUF) kept in HBM and
+ * fed straight from the step kernel's outputs, and the marshalling the driver does around
+ * env.step() (TRAIN:1386-1396, 1601-1608, 1776-1799).
+ * =========================================================================================== */
+typedef struct RisVecReplay {            /* BUF:4-14; device pointers, row r of every array = transition r */
+    int32_t n_agents, input_shape, n_actions;   /* state row = input_shape*n_agents floats, action row = n_actions*n_agents */
+    int32_t reserved;
+    int64_t mem_size;
+    float *state_memory;                /* [mem_size, input_shape*n_agents]  */
+    float *action_memory;               /* [mem_size, n_actions*n_agents]    */
+    float *reward_global_memory;        /* [mem_size]                        */
+    float *reward_local_memory;         /* [mem_size, n_agents]              */
+    float *new_state_memory;            /* [mem_size, input_shape*n_agents]  */
+    uint8_t *terminal_memory;           /* [mem_size] 0/1                    */
+    float *mask_memory;                 /* [mem_size, n_agents*n_agents]     */
+} RisVecReplay;
+
+/* n consecutive store_transition calls (BUF:16-25), transition e landing in row (mem_cntr + e) % mem_size;
+ * the caller advances its mem_cntr by n.  n <= mem_size.  reward_g is read with a stride (in floats) so
+ * metrics[:,0] can be passed as is; done [n] 0/1 or NULL (then done_all applies to every transition);
+ * mask [n, A*A] 0/1 bytes (the NOMA mask) or NULL = all ones (TRAIN:1786-1787). */
+int risvec_replay_store(const RisVecReplay *rb, int64_t mem_cntr, int32_t n, const float *state, const float *action,
+                        const float *reward_g, int32_t reward_g_stride, const float *reward_l, const float *state_,
+                        const uint8_t *done, int32_t done_all, const uint8_t *mask, risvec_stream_t stream);
+
+/* sample_buffer (BUF:27-37): rows idx[b] (int64, each < max_mem = min(mem_cntr, mem_size)) or, with
+ * idx NULL, Philox(seed; b, 0, counter, site 8) -> floor(x * max_mem / 2^32); outputs [batch, ...] in the
+ * order sample_buffer returns them; idx_out (or NULL) receives the rows used. */
+int risvec_replay_sample(const RisVecReplay *rb, int64_t max_mem, int32_t batch, const int64_t *idx, uint64_t seed,
+                         uint32_t counter, float *states, float *actions, float *rewards_g, float *rewards_l,
+                         float *states_, uint8_t *dones, float *masks, int64_t *idx_out, risvec_stream_t stream);
+
+/* Policy outputs -> the three places the driver sends them: power_raw [E,V,2] (SAC power head, in
+ * [-1,1]), probs [E,V,V] (intent probabilities) ->
+ *   action_env   [E,2,V]      TRAIN:1601-1608  clip to +-0.999, (x+1)/2, CPU share floored at clamp(floor,0,0.95)
+ *   p_off01      [E,V]        TRAIN:1391-1396  (input of the NOMA QoS check)
+ *   action_store [E,V*(V+2)]  TRAIN:1386-1390, 1776-1784  per agent [probs_i with zero diagonal, raw power_i]
+ * any output may be NULL; probs may be NULL when action_store is. */
+int risvec_marshal_actions(int32_t n_envs, int32_t n_veh, const float *power_raw, const float *probs,
+                           float cpu_share_floor, float *action_env, float *p_off01, float *action_store,
+                           risvec_stream_t stream);
 
 #ifdef __cplusplus
 }

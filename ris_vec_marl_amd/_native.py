@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -100,6 +100,15 @@ class RisVecNomaState(C.Structure):
     ]
 
 
+class RisVecReplay(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int32), ("input_shape", C.c_int32), ("n_actions", C.c_int32), ("reserved", C.c_int32),
+        ("mem_size", C.c_int64),
+        ("state_memory", _FP), ("action_memory", _FP), ("reward_global_memory", _FP), ("reward_local_memory", _FP),
+        ("new_state_memory", _FP), ("terminal_memory", _FP), ("mask_memory", _FP),
+    ]
+
+
 NOMA_MAX_VEH = 16
 NOMA_HAS_LAST, NOMA_UNSTICK_USED, NOMA_HAS_GROUPS = 1, 2, 4
 
@@ -137,6 +146,11 @@ _PROTOS = {
                                     C.c_int32, C.c_int32, _FP, _FP, C.c_int32, C.c_int32, _FP,
                                     C.c_uint64, C.c_uint32, _FP, _FP]),
     "risvec_noma_flush": (C.c_int, [C.POINTER(RisVecNomaState), C.POINTER(RisVecNomaParams), _FP]),
+    "risvec_replay_store": (C.c_int, [C.POINTER(RisVecReplay), C.c_int64, C.c_int32, _FP, _FP, _FP, C.c_int32, _FP,
+                                      _FP, _FP, C.c_int32, _FP, _FP]),
+    "risvec_replay_sample": (C.c_int, [C.POINTER(RisVecReplay), C.c_int64, C.c_int32, _FP, C.c_uint64, C.c_uint32,
+                                       _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "risvec_marshal_actions": (C.c_int, [C.c_int32, C.c_int32, _FP, _FP, C.c_float, _FP, _FP, _FP, _FP]),
 }
 
 EXPORTS = tuple(_PROTOS)   # every symbol include/risvec.h declares

@@ -391,4 +391,69 @@ int risvec_noma_flush(const RisVecNomaState* ns, const RisVecNomaParams* np, ris
     return finish(fn, risvec::launch_noma_flush(*ns, np->pair_hist_decay, (hipStream_t)stream));
 }
 
+// ---------------------------------------------------------------------------------------------
+// replay ring buffer + marshalling (f3)
+// ---------------------------------------------------------------------------------------------
+static int check_replay(const char* fn, const RisVecReplay* rb) {
+    if (!rb) return fail(RISVEC_ERR_ARG, "%s: replay is NULL", fn);
+    if (rb->n_agents < 1 || rb->n_agents > RISVEC_MAX_VEH || rb->input_shape < 1 || rb->n_actions < 1)
+        return fail(RISVEC_ERR_SHAPE, "%s: n_agents=%d input_shape=%d n_actions=%d", fn, rb->n_agents, rb->input_shape,
+                    rb->n_actions);
+    if (rb->mem_size < 1) return fail(RISVEC_ERR_SHAPE, "%s: mem_size=%lld must be >= 1", fn, (long long)rb->mem_size);
+    REQ_PTR(rb->state_memory, "replay.state_memory"); REQ_PTR(rb->action_memory, "replay.action_memory");
+    REQ_PTR(rb->reward_global_memory, "replay.reward_global_memory");
+    REQ_PTR(rb->reward_local_memory, "replay.reward_local_memory");
+    REQ_PTR(rb->new_state_memory, "replay.new_state_memory"); REQ_PTR(rb->terminal_memory, "replay.terminal_memory");
+    REQ_PTR(rb->mask_memory, "replay.mask_memory");
+    return RISVEC_OK;
+}
+
+int risvec_replay_store(const RisVecReplay* rb, int64_t mem_cntr, int32_t n, const float* state, const float* action,
+                        const float* reward_g, int32_t reward_g_stride, const float* reward_l, const float* state_,
+                        const uint8_t* done, int32_t done_all, const uint8_t* mask, risvec_stream_t stream) {
+    const char* fn = "risvec_replay_store";
+    if (int rc = check_replay(fn, rb)) return rc;
+    if (n < 1 || n > rb->mem_size)
+        return fail(RISVEC_ERR_SHAPE, "%s: n=%d outside [1, mem_size=%lld] (a batch may not overwrite itself)", fn, n,
+                    (long long)rb->mem_size);
+    if (mem_cntr < 0) return fail(RISVEC_ERR_ARG, "%s: mem_cntr=%lld must be >= 0", fn, (long long)mem_cntr);
+    if (reward_g_stride < 1) return fail(RISVEC_ERR_ARG, "%s: reward_g_stride=%d must be >= 1", fn, reward_g_stride);
+    REQ_PTR(state, "state"); REQ_PTR(action, "action"); REQ_PTR(reward_l, "reward_l"); REQ_PTR(state_, "state_");
+    if (!reward_g || (reinterpret_cast<uintptr_t>(reward_g) & 3u))
+        return fail(RISVEC_ERR_ARG, "%s: reward_g is NULL or not 4-byte aligned", fn);
+    return finish(fn, risvec::launch_replay_store(*rb, mem_cntr, n, state, action, reward_g, reward_g_stride, reward_l,
+                                                  state_, done, done_all, mask, (hipStream_t)stream));
+}
+
+int risvec_replay_sample(const RisVecReplay* rb, int64_t max_mem, int32_t batch, const int64_t* idx, uint64_t seed,
+                         uint32_t counter, float* states, float* actions, float* rewards_g, float* rewards_l,
+                         float* states_, uint8_t* dones, float* masks, int64_t* idx_out, risvec_stream_t stream) {
+    const char* fn = "risvec_replay_sample";
+    if (int rc = check_replay(fn, rb)) return rc;
+    if (batch < 1) return fail(RISVEC_ERR_SHAPE, "%s: batch=%d must be >= 1", fn, batch);
+    if (max_mem < 1 || max_mem > rb->mem_size)
+        return fail(RISVEC_ERR_ARG, "%s: max_mem=%lld outside [1, mem_size=%lld] (sampling an empty buffer?)", fn,
+                    (long long)max_mem, (long long)rb->mem_size);
+    OPT_PTR(idx, "idx"); OPT_PTR(idx_out, "idx_out");
+    REQ_PTR(states, "states"); REQ_PTR(actions, "actions"); REQ_PTR(rewards_g, "rewards_g");
+    REQ_PTR(rewards_l, "rewards_l"); REQ_PTR(states_, "states_"); REQ_PTR(dones, "dones"); REQ_PTR(masks, "masks");
+    return finish(fn, risvec::launch_replay_sample(*rb, max_mem, batch, idx, seed, counter, states, actions, rewards_g,
+                                                   rewards_l, states_, dones, masks, idx_out, (hipStream_t)stream));
+}
+
+int risvec_marshal_actions(int32_t n_envs, int32_t n_veh, const float* power_raw, const float* probs,
+                           float cpu_share_floor, float* action_env, float* p_off01, float* action_store,
+                           risvec_stream_t stream) {
+    const char* fn = "risvec_marshal_actions";
+    if (n_envs < 1) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d must be >= 1", fn, n_envs);
+    if (n_veh < 1 || n_veh > RISVEC_MAX_VEH)
+        return fail(RISVEC_ERR_SHAPE, "%s: n_veh=%d outside [1,%d]", fn, n_veh, RISVEC_MAX_VEH);
+    REQ_PTR(power_raw, "power_raw"); OPT_PTR(probs, "probs"); OPT_PTR(action_env, "action_env");
+    OPT_PTR(p_off01, "p_off01"); OPT_PTR(action_store, "action_store");
+    if (action_store && !probs) return fail(RISVEC_ERR_ARG, "%s: action_store needs probs", fn);
+    const float fl = cpu_share_floor < 0.0f ? 0.0f : (cpu_share_floor > 0.95f ? 0.95f : cpu_share_floor);
+    return finish(fn, risvec::launch_marshal_actions(n_envs, n_veh, power_raw, probs, fl, action_env, p_off01,
+                                                     action_store, (hipStream_t)stream));
+}
+
 }  // extern "C"

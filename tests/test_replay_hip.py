@@ -1,0 +1,113 @@
+"""GPU parity tests of the replay ring buffer + marshalling: bit-exact against
+the vectors captured from the reference's own buffer.py / marshalling statements and against
+oracle/replay_oracle.py at BASELINE batch sizes."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import replay_oracle as RO  # noqa: E402  (checker)
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+ARRAYS = ("state_memory", "action_memory", "reward_global_memory", "reward_local_memory", "new_state_memory",
+          "terminal_memory", "mask_memory")
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "replay_buffer_*.npz"))), ids=os.path.basename)
+@pytest.mark.parametrize("chunk", [1, 37])
+def test_ring_vs_golden(path, chunk):
+    from ris_vec_marl_amd import VecReplayBuffer
+    d = np.load(path)
+    V, cap = int(d["V"]), int(d["cap"])
+    buf = VecReplayBuffer(cap, 5, V + 2, V, device=DEV)
+    n = len(d["state"])
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        if chunk == 1:          # the reference's own signature, one transition at a time
+            buf.store_transition(d["state"][lo], d["action"][lo], float(d["reward_g"][lo]), d["reward_l"][lo],
+                                 d["state_"][lo], bool(d["done"][lo]), d["mask"][lo])
+        else:
+            buf.store_batch(T(d["state"][lo:hi]), T(d["action"][lo:hi]), T(d["reward_g"][lo:hi]), T(d["reward_l"][lo:hi]),
+                            T(d["state_"][lo:hi]), T(d["done"][lo:hi]), T(d["mask"][lo:hi].reshape(-1, V, V)))
+    assert buf.mem_cntr == int(d["mem_cntr"])
+    for k in ARRAYS:
+        assert np.array_equal(getattr(buf, k).cpu().numpy(), d[k]), k
+    out = buf.sample_buffer(len(d["batch"]), idx=T(d["batch"].astype(np.int64)))
+    for got, k in zip(out, ("s_states", "s_actions", "s_rewards_g", "s_rewards_l", "s_states_", "s_dones", "s_masks")):
+        assert np.array_equal(got.cpu().numpy(), d[k]), k
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "replay_marshal_*.npz"))), ids=os.path.basename)
+def test_marshal_vs_golden(path):
+    from ris_vec_marl_amd import marshal_actions
+    d = np.load(path)
+    for fl in np.unique(d["floor"]):
+        sel = d["floor"] == fl
+        env_a, p01, store = marshal_actions(T(d["power"][sel]), T(d["probs"][sel]), float(fl))
+        # the reference holds float32-valued numbers in a float64 array; the floor itself is a double
+        assert np.array_equal(env_a.cpu().numpy(), d["action_env"][sel].astype(np.float32))
+        assert np.array_equal(p01.cpu().numpy(), d["action_env"][sel][:, 0, :].astype(np.float32))
+        assert np.array_equal(store.cpu().numpy(), d["store"][sel])
+
+
+def test_full_size_from_env_outputs():
+    """E = 32 768 transitions per step taken in place from a stepped VecEnviron (obs, reward,
+    metrics[:,0], NOMA mask), 5 steps into a ring that wraps; device Philox sampling; all against
+    the oracle fed the same arrays."""
+    from ris_vec_marl_amd import NomaGrouper, VecEnviron, VecReplayBuffer, marshal_actions, reference_lanes
+    E, V, M = 32768, 8, 64
+    L = reference_lanes()
+    env = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3,
+                     n_envs=E, device=DEV, seed=9)
+    env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase(); env.update_channel_gains()
+    grouper = NomaGrouper(env)
+    grouper.begin_episode(0)
+    cap = 3 * E + 1000
+    buf = VecReplayBuffer(cap, 5, V + 2, V, device=DEV, seed=123)
+    orc = RO.ReplayOracle(cap, 5, V + 2, V)
+    rng = np.random.default_rng(5)
+    obs_old = env.tensors["obs"].clone()
+    for t in range(5):
+        power = T(rng.uniform(-1.1, 1.1, (E, V, 2)).astype(np.float32))
+        probs = T(rng.dirichlet(np.ones(V), (E, V)).astype(np.float32))
+        action_env, p01, store = marshal_actions(power, probs, env.cpu_share_floor)
+        a_o, p_o, s_o = RO.marshal_actions(power.cpu().numpy(), probs.cpu().numpy(), env.cpu_share_floor)
+        assert np.array_equal(action_env.cpu().numpy(), a_o.astype(np.float32))
+        assert np.array_equal(store.cpu().numpy(), s_o)
+        mask = grouper.refresh_mask() if t % 2 == 0 else None
+        partner, ng = grouper.group(p01, t)
+        env.step(action_env, partner, ng, None, fused=True)
+        obs_new, reward, metrics = env.tensors["obs"], env.tensors["reward"], env.tensors["metrics"]
+        done = t == 4
+        buf.store_batch(obs_old, store, metrics, reward, obs_new, done, mask)
+        orc.store_batch(obs_old.cpu().numpy().reshape(E, -1), s_o, metrics[:, 0].cpu().numpy(), reward.cpu().numpy(),
+                        obs_new.cpu().numpy().reshape(E, -1), done,
+                        None if mask is None else mask.cpu().numpy().reshape(E, -1).astype(np.float32))
+        obs_old = obs_new.clone()
+    assert buf.mem_cntr == orc.mem_cntr == 5 * E
+    for k in ARRAYS:
+        assert np.array_equal(getattr(buf, k).cpu().numpy(), getattr(orc, k)), k
+    out = buf.sample_buffer(4096)
+    rows = buf.last_batch.cpu().numpy()
+    assert np.array_equal(rows, RO.philox_sample_indices(4096, orc.max_mem(), 1, 123))
+    for got, exp in zip(out, orc.sample(rows)):
+        assert np.array_equal(got.cpu().numpy(), exp)
+
+
+def test_errors():
+    from ris_vec_marl_amd import VecReplayBuffer
+    buf = VecReplayBuffer(16, 5, 6, 4, device=DEV)
+    with pytest.raises(ValueError):
+        buf.sample_buffer(4)                                   # empty
+    z = torch.zeros(17, 20, device=DEV)
+    with pytest.raises(ValueError):                            # a batch may not overwrite itself
+        buf.store_batch(z, torch.zeros(17, 24, device=DEV), torch.zeros(17, device=DEV), torch.zeros(17, 4, device=DEV), z)
