@@ -170,7 +170,12 @@ def main() -> None:
     ap.add_argument("--noma", action="store_true",
                     help="also run the NOMA grouping stage (SURVEY 8 f2) before every step, with the reference's "
                          "episode structure: 100-step episodes, mask rebuilt at step 0, groups frozen in between")
+    ap.add_argument("--replay", action="store_true",
+                    help="full device-resident rollout step (SURVEY 8 f3): marshal synthetic policy outputs, group "
+                         "(implies --noma), step, append the E transitions to the HBM replay ring")
     args = ap.parse_args()
+    if args.replay:
+        args.noma = True
 
     from ris_vec_marl_amd import dist as rdist
     rank, world, local = rdist.init_from_env()
@@ -223,6 +228,18 @@ def main() -> None:
         grouper.begin_episode(0); grouper.refresh_mask()
         partner, n_groups = grouper.group(action[:, 0, :].contiguous(), 0)     # state views: stable pointers
     p_off01 = action[:, 0, :].contiguous()
+    marshal = store = None
+    if args.replay:
+        from ris_vec_marl_amd import VecReplayBuffer, marshal_actions
+        power_raw = torch.from_numpy(rng.uniform(-1, 1, (E, V, 2)).astype(np.float32)).to(device)
+        probs = torch.from_numpy(rng.dirichlet(np.ones(V), (E, V)).astype(np.float32)).to(device)
+        a_store = torch.empty(E, V * (V + 2), device=device)
+        floor = float(env.cpu_share_floor)
+        marshal = lambda: marshal_actions(power_raw, probs, floor, out=(action, p_off01, a_store))   # noqa: E731
+        marshal()
+        replay = VecReplayBuffer(16 * E, 5, V + 2, V, device=device)
+        store = replay.bind_store(None, a_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"],
+                                  grouper.mask)
     group = grouper.bind_group(p_off01) if grouper is not None else None
     launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full, power_w=False,
                            obs=full)
@@ -234,8 +251,12 @@ def main() -> None:
             if t == 0:
                 grouper.begin_episode(i // episode_len)
                 grouper.refresh_mask()
+            if marshal is not None:
+                marshal()
             group(t)
         launch()
+        if store is not None:
+            store(done=(i % episode_len) == episode_len - 1, use_mask=(i % episode_len) == 0)
         if gather is not None and i % args.gather_every == 0:
             gather.start(env.tensors["obs"])
 
@@ -297,6 +318,8 @@ def main() -> None:
                    "envs_per_gpu": E, "n_veh": V, "n_ris": M, "mode": args.mode, "allgather": gather_note,
                    "noma_grouping": ("device, every step, 100-step episodes (config.yaml pairing keys)"
                                      if args.noma else "synthetic fixed groups"),
+                   "replay": ("marshal + HBM replay ring store every step (%d B per transition)"
+                              % (4 * (10 * V + V * (V + 2) + V + 1 + V * V) + 1) if args.replay else "off"),
                    "agent_steps_per_s": E * world * args.steps / dt * V},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -400,10 +400,13 @@ typedef struct RisVecReplay {            /* BUF:4-14; device pointers, row r of 
 /* n consecutive store_transition calls (BUF:16-25), transition e landing in row (mem_cntr + e) % mem_size;
  * the caller advances its mem_cntr by n.  n <= mem_size.  reward_g is read with a stride (in floats) so
  * metrics[:,0] can be passed as is; done [n] 0/1 or NULL (then done_all applies to every transition);
- * mask [n, A*A] 0/1 bytes (the NOMA mask) or NULL = all ones (TRAIN:1786-1787). */
+ * mask [n, A*A] 0/1 bytes (the NOMA mask) or NULL = all ones (TRAIN:1786-1787); state_carry (or NULL)
+ * receives a copy of state_ -- the next step's `state` (marl_state_old_all, TRAIN:1277) without a
+ * separate copy; it must not alias state / state_. */
 int risvec_replay_store(const RisVecReplay *rb, int64_t mem_cntr, int32_t n, const float *state, const float *action,
                         const float *reward_g, int32_t reward_g_stride, const float *reward_l, const float *state_,
-                        const uint8_t *done, int32_t done_all, const uint8_t *mask, risvec_stream_t stream);
+                        const uint8_t *done, int32_t done_all, const uint8_t *mask, float *state_carry,
+                        risvec_stream_t stream);
 
 /* sample_buffer (BUF:27-37): rows idx[b] (int64, each < max_mem = min(mem_cntr, mem_size)) or, with
  * idx NULL, Philox(seed; b, 0, counter, site 8) -> floor(x * max_mem / 2^32); outputs [batch, ...] in the

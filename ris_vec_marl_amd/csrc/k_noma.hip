@@ -83,10 +83,8 @@ __device__ __forceinline__ float replay_hist(float h, int pending, float decay, 
 // ---------------------------------------------------------------------------------------------
 // pre: one lane per env
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-k_noma_pre(NomaArgs A) {
-    const int env = blockIdx.x * kBlock + threadIdx.x;
-    if (env >= A.ns.n_envs) return;
+// The per-env part of k_noma_pre; returns true when the env has to (re)solve its pairing.
+__device__ __forceinline__ bool noma_pre_env(const NomaArgs& A, int env) {
     const RisVecNomaParams& P = A.P;
     int flags = A.ns.flags[env];
     double last = A.ns.last_global[env], best = A.ns.best_global[env];
@@ -123,10 +121,27 @@ k_noma_pre(NomaArgs A) {
             int* o = A.info_out + (long long)env * 4;
             o[0] = 0; o[1] = 0; o[2] = A.ns.n_veh - A.ns.n_groups[env]; o[3] = 0;
         }
-    } else {
-        const int k = atomicAdd(A.ns.todo + A.ns.n_envs, 1);
-        A.ns.todo[k] = env;
+        return false;
     }
+    return true;
+}
+
+
+__global__ void __launch_bounds__(kBlock)
+k_noma_pre(NomaArgs A) {
+    const int env = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = env < A.ns.n_envs;
+    bool solve = false;
+    if (live) solve = noma_pre_env(A, env);
+    // append to the to-do list: one atomic per wavefront, not per env (on the first steps of an
+    // episode every env re-solves and 32 768 atomics on one word would dominate this kernel)
+    const unsigned long long m = __ballot(solve);
+    if (m == 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(A.ns.todo + A.ns.n_envs, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1, kWave);
+    if (solve) A.ns.todo[base + __popcll(m & ((1ull << lane) - 1))] = env;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -20,40 +20,73 @@ struct StoreArgs {
     int n;
     const float* state; const float* action; const float* reward_g; int rg_stride; const float* reward_l;
     const float* state_; const uint8_t* done; int done_all; const uint8_t* mask;
+    float* carry;                // optional [n, input_shape*n_agents]: receives a copy of state_
 };
 
+// Segment-major copy: word g of a source array [n, len] lands at row (cursor + g / len) % mem_size.
+// The n rows are consecutive in the ring, so there is at most one wrap: words before it go to
+// head + g, the rest to g - (words before the wrap) -- no division on the copy path.  With every row
+// length a multiple of 4 (n_agents % 4 == 0) a lane moves 16 bytes; the two scalar-per-transition
+// arrays (reward_g, done) are handled by the lanes after the vector part.
+template <int VEC> struct Pack { using F = float; using U = uint8_t; };
+template <> struct Pack<4> { using F = float4; using U = uchar4; };
+
+template <int VEC>
+__device__ __forceinline__ typename Pack<VEC>::F widen(typename Pack<VEC>::U m);
+template <> __device__ __forceinline__ float widen<1>(uint8_t m) { return m ? 1.0f : 0.0f; }
+template <> __device__ __forceinline__ float4 widen<4>(uchar4 m) {
+    return make_float4(m.x ? 1.0f : 0.0f, m.y ? 1.0f : 0.0f, m.z ? 1.0f : 0.0f, m.w ? 1.0f : 0.0f);
+}
+template <int VEC> __device__ __forceinline__ typename Pack<VEC>::F ones();
+template <> __device__ __forceinline__ float ones<1>() { return 1.0f; }
+template <> __device__ __forceinline__ float4 ones<4>() { return make_float4(1.0f, 1.0f, 1.0f, 1.0f); }
+
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_replay_store(StoreArgs A) {
+    using F = typename Pack<VEC>::F;
+    using U = typename Pack<VEC>::U;
     const RisVecReplay& rb = A.rb;
     const long long S = (long long)rb.input_shape * rb.n_agents, Ac = (long long)rb.n_actions * rb.n_agents;
     const long long L = rb.n_agents, M = (long long)rb.n_agents * rb.n_agents, n = A.n;
-    // segment boundaries in the flat word space: state | action | reward_l | state_ | mask | reward_g | done
-    const long long b0 = n * S, b1 = b0 + n * Ac, b2 = b1 + n * L, b3 = b2 + n * S, b4 = b3 + n * M, b5 = b4 + n,
-                    b6 = b5 + n;
+    // segment boundaries in the flat word space: state | action | reward_l | state_ | mask || reward_g | done
+    const long long b0 = n * S, b1 = b0 + n * Ac, b2 = b1 + n * L, b3 = b2 + n * S, b4 = b3 + n * M;
+    const long long units = b4 / VEC;                          // vector part (VEC divides every row length)
     const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= b6) return;
-    auto row_of = [&](long long e) { return (A.cursor + e) % rb.mem_size; };
-    if (gid < b0) {
-        const long long e = gid / S, k = gid % S;
-        rb.state_memory[row_of(e) * S + k] = A.state[gid];
-    } else if (gid < b1) {
-        const long long g = gid - b0, e = g / Ac, k = g % Ac;
-        rb.action_memory[row_of(e) * Ac + k] = A.action[g];
-    } else if (gid < b2) {
-        const long long g = gid - b1, e = g / L, k = g % L;
-        rb.reward_local_memory[row_of(e) * L + k] = A.reward_l[g];
-    } else if (gid < b3) {
-        const long long g = gid - b2, e = g / S, k = g % S;
-        rb.new_state_memory[row_of(e) * S + k] = A.state_[g];
-    } else if (gid < b4) {
-        const long long g = gid - b3, e = g / M, k = g % M;
-        rb.mask_memory[row_of(e) * M + k] = A.mask ? (A.mask[g] ? 1.0f : 0.0f) : 1.0f;    // TRAIN:1786-1789
-    } else if (gid < b5) {
-        const long long e = gid - b4;
-        rb.reward_global_memory[row_of(e)] = A.reward_g[e * A.rg_stride];
-    } else {
-        const long long e = gid - b5;
-        rb.terminal_memory[row_of(e)] = A.done ? (A.done[e] ? 1 : 0) : (A.done_all ? 1 : 0);
+    const long long head = A.cursor % rb.mem_size;             // ring row of transition 0 (uniform)
+    const long long rows_to_wrap = rb.mem_size - head;         // transitions that fit before the wrap
+    auto dest = [&](long long g, long long len) {
+        const long long before = rows_to_wrap * len;
+        return g < before ? head * len + g : g - before;
+    };
+    if (gid < units) {
+        const long long w = gid * VEC;
+        if (w < b0) {
+            *reinterpret_cast<F*>(rb.state_memory + dest(w, S)) = *reinterpret_cast<const F*>(A.state + w);
+        } else if (w < b1) {
+            const long long g = w - b0;
+            *reinterpret_cast<F*>(rb.action_memory + dest(g, Ac)) = *reinterpret_cast<const F*>(A.action + g);
+        } else if (w < b2) {
+            const long long g = w - b1;
+            *reinterpret_cast<F*>(rb.reward_local_memory + dest(g, L)) = *reinterpret_cast<const F*>(A.reward_l + g);
+        } else if (w < b3) {
+            const long long g = w - b2;
+            const F v = *reinterpret_cast<const F*>(A.state_ + g);
+            *reinterpret_cast<F*>(rb.new_state_memory + dest(g, S)) = v;
+            if (A.carry) *reinterpret_cast<F*>(A.carry + g) = v;      // next step's `state`, for free
+        } else {
+            const long long g = w - b3;
+            *reinterpret_cast<F*>(rb.mask_memory + dest(g, M)) =
+                A.mask ? widen<VEC>(*reinterpret_cast<const U*>(A.mask + g)) : ones<VEC>();    // TRAIN:1786-1789
+        }
+        return;
+    }
+    const long long t = gid - units;
+    if (t < n) {
+        rb.reward_global_memory[dest(t, 1)] = A.reward_g[t * A.rg_stride];
+    } else if (t < 2 * n) {
+        const long long e = t - n;
+        rb.terminal_memory[dest(e, 1)] = A.done ? (A.done[e] ? 1 : 0) : (A.done_all ? 1 : 0);
     }
 }
 
@@ -114,20 +147,17 @@ k_replay_sample(SampleArgs A) {
 __global__ void __launch_bounds__(kBlock)
 k_marshal_actions(int E, int V, const float* power_raw, const float* probs, float floor_eff, float* action_env,
                   float* p_off01, float* action_store) {
-    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const int W = V + 2;
-    if (gid >= (long long)E * V * W) return;
-    const int k = (int)(gid % W);
-    const long long ev = gid / W;
-    const int v = (int)(ev % V);
-    const long long e = ev / V;
+    const unsigned gid = blockIdx.x * kBlock + threadIdx.x;   // E*V*(V+2) < 2^31 is checked by the API
+    const unsigned W = V + 2;
+    if (gid >= (unsigned)E * V * W) return;
+    const unsigned k = gid % W, ev = gid / W, v = ev % V, e = ev / V;
     if (action_store) {
         float out;
-        if (k < V) out = k == v ? 0.0f : probs[ev * V + k];              // np.fill_diagonal(., 0), TRAIN:1390
+        if (k < (unsigned)V) out = k == v ? 0.0f : probs[ev * V + k];              // np.fill_diagonal(., 0), TRAIN:1390
         else out = power_raw[ev * 2 + (k - V)];                          // raw policy output, TRAIN:1777-1782
         action_store[gid] = out;
     }
-    if (k == V) {
+    if (k == (unsigned)V) {
         const float a0 = power_raw[ev * 2], a1 = power_raw[ev * 2 + 1];
         const float m0 = (fminf(fmaxf(a0, -0.999f), 0.999f) + 1.0f) / 2.0f;    // TRAIN:1603-1605
         const float m1 = (fminf(fmaxf(a1, -0.999f), 0.999f) + 1.0f) / 2.0f;
@@ -139,15 +169,49 @@ k_marshal_actions(int E, int V, const float* power_raw, const float* probs, floa
     }
 }
 
+// Even V: one lane per (env, agent) moves that agent's whole row with 8-byte accesses (probs row in,
+// [probs | power] row out: both start on 8-byte boundaries when V is even).
+__global__ void __launch_bounds__(kBlock)
+k_marshal_rows(int E, int V, const float* power_raw, const float* probs, float floor_eff, float* action_env,
+               float* p_off01, float* action_store) {
+    const unsigned ev = blockIdx.x * kBlock + threadIdx.x;
+    if (ev >= (unsigned)E * V) return;
+    const unsigned v = ev % V, e = ev / V;
+    const float2 pw = *reinterpret_cast<const float2*>(power_raw + (size_t)ev * 2);
+    if (action_store) {
+        const float2* src = reinterpret_cast<const float2*>(probs + (size_t)ev * V);
+        float2* dst = reinterpret_cast<float2*>(action_store + (size_t)ev * (V + 2));
+        for (unsigned k2 = 0; k2 < (unsigned)V / 2; ++k2) {
+            float2 p = src[k2];
+            if (2 * k2 == v) p.x = 0.0f;                               // np.fill_diagonal(., 0), TRAIN:1390
+            if (2 * k2 + 1 == v) p.y = 0.0f;
+            dst[k2] = p;
+        }
+        dst[V / 2] = pw;                                               // raw policy output, TRAIN:1777-1782
+    }
+    const float m0 = (fminf(fmaxf(pw.x, -0.999f), 0.999f) + 1.0f) / 2.0f;       // TRAIN:1603-1605
+    const float m1 = (fminf(fmaxf(pw.y, -0.999f), 0.999f) + 1.0f) / 2.0f;
+    if (action_env) {
+        action_env[((size_t)e * 2 + 0) * V + v] = m0;
+        action_env[((size_t)e * 2 + 1) * V + v] = fmaxf(m1, floor_eff);          // TRAIN:1606-1608
+    }
+    if (p_off01) p_off01[ev] = m0;                                              // TRAIN:1393-1396
+}
+
 }  // namespace
 
 hipError_t launch_replay_store(const RisVecReplay& rb, long long cursor, int n, const float* state, const float* action,
                                const float* reward_g, int rg_stride, const float* reward_l, const float* state_,
-                               const uint8_t* done, int done_all, const uint8_t* mask, hipStream_t st) {
+                               const uint8_t* done, int done_all, const uint8_t* mask, float* carry, hipStream_t st) {
     const long long S = (long long)rb.input_shape * rb.n_agents, Ac = (long long)rb.n_actions * rb.n_agents;
-    const long long words = (long long)n * (2 * S + Ac + rb.n_agents + (long long)rb.n_agents * rb.n_agents + 2);
-    StoreArgs a{rb, cursor, n, state, action, reward_g, rg_stride, reward_l, state_, done, done_all, mask};
-    hipLaunchKernelGGL(k_replay_store, dim3((unsigned)((words + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a);
+    const long long L = rb.n_agents, M = L * L;
+    const long long words = (long long)n * (2 * S + Ac + L + M);
+    StoreArgs a{rb, cursor, n, state, action, reward_g, rg_stride, reward_l, state_, done, done_all, mask, carry};
+    const bool vec = S % 4 == 0 && Ac % 4 == 0 && L % 4 == 0;      // then M = L*L is too
+    const long long threads = (vec ? words / 4 : words) + 2LL * n;
+    const dim3 grid((unsigned)((threads + kBlock - 1) / kBlock));
+    if (vec) hipLaunchKernelGGL(k_replay_store<4>, grid, dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL(k_replay_store<1>, grid, dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }
 
@@ -164,6 +228,12 @@ hipError_t launch_replay_sample(const RisVecReplay& rb, long long max_mem, int b
 
 hipError_t launch_marshal_actions(int E, int V, const float* power_raw, const float* probs, float floor_eff,
                                   float* action_env, float* p_off01, float* action_store, hipStream_t st) {
+    if (V % 2 == 0) {
+        const long long rows = (long long)E * V;
+        hipLaunchKernelGGL(k_marshal_rows, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, E, V,
+                           power_raw, probs, floor_eff, action_env, p_off01, action_store);
+        return hipGetLastError();
+    }
     const long long words = (long long)E * V * (V + 2);
     hipLaunchKernelGGL(k_marshal_actions, dim3((unsigned)((words + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, E, V,
                        power_raw, probs, floor_eff, action_env, p_off01, action_store);

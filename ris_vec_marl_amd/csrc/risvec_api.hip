@@ -410,7 +410,8 @@ static int check_replay(const char* fn, const RisVecReplay* rb) {
 
 int risvec_replay_store(const RisVecReplay* rb, int64_t mem_cntr, int32_t n, const float* state, const float* action,
                         const float* reward_g, int32_t reward_g_stride, const float* reward_l, const float* state_,
-                        const uint8_t* done, int32_t done_all, const uint8_t* mask, risvec_stream_t stream) {
+                        const uint8_t* done, int32_t done_all, const uint8_t* mask, float* state_carry,
+                        risvec_stream_t stream) {
     const char* fn = "risvec_replay_store";
     if (int rc = check_replay(fn, rb)) return rc;
     if (n < 1 || n > rb->mem_size)
@@ -419,10 +420,13 @@ int risvec_replay_store(const RisVecReplay* rb, int64_t mem_cntr, int32_t n, con
     if (mem_cntr < 0) return fail(RISVEC_ERR_ARG, "%s: mem_cntr=%lld must be >= 0", fn, (long long)mem_cntr);
     if (reward_g_stride < 1) return fail(RISVEC_ERR_ARG, "%s: reward_g_stride=%d must be >= 1", fn, reward_g_stride);
     REQ_PTR(state, "state"); REQ_PTR(action, "action"); REQ_PTR(reward_l, "reward_l"); REQ_PTR(state_, "state_");
+    OPT_PTR(state_carry, "state_carry"); OPT_PTR(mask, "mask");
+    if (state_carry == state || state_carry == state_)
+        return fail(RISVEC_ERR_ARG, "%s: state_carry must not alias state / state_ (other lanes are reading them)", fn);
     if (!reward_g || (reinterpret_cast<uintptr_t>(reward_g) & 3u))
         return fail(RISVEC_ERR_ARG, "%s: reward_g is NULL or not 4-byte aligned", fn);
     return finish(fn, risvec::launch_replay_store(*rb, mem_cntr, n, state, action, reward_g, reward_g_stride, reward_l,
-                                                  state_, done, done_all, mask, (hipStream_t)stream));
+                                                  state_, done, done_all, mask, state_carry, (hipStream_t)stream));
 }
 
 int risvec_replay_sample(const RisVecReplay* rb, int64_t max_mem, int32_t batch, const int64_t* idx, uint64_t seed,
@@ -451,6 +455,8 @@ int risvec_marshal_actions(int32_t n_envs, int32_t n_veh, const float* power_raw
     REQ_PTR(power_raw, "power_raw"); OPT_PTR(probs, "probs"); OPT_PTR(action_env, "action_env");
     OPT_PTR(p_off01, "p_off01"); OPT_PTR(action_store, "action_store");
     if (action_store && !probs) return fail(RISVEC_ERR_ARG, "%s: action_store needs probs", fn);
+    if ((long long)n_envs * n_veh * (n_veh + 2) >= (1LL << 31))
+        return fail(RISVEC_ERR_SHAPE, "%s: n_envs*n_veh*(n_veh+2) must stay below 2^31", fn);
     const float fl = cpu_share_floor < 0.0f ? 0.0f : (cpu_share_floor > 0.95f ? 0.95f : cpu_share_floor);
     return finish(fn, risvec::launch_marshal_actions(n_envs, n_veh, power_raw, probs, fl, action_env, p_off01,
                                                      action_store, (hipStream_t)stream));

@@ -54,7 +54,7 @@ hipError_t launch_noma_flush(const RisVecNomaState& ns, float decay, hipStream_t
 
 hipError_t launch_replay_store(const RisVecReplay& rb, long long cursor, int n, const float* state, const float* action,
                                const float* reward_g, int rg_stride, const float* reward_l, const float* state_,
-                               const uint8_t* done, int done_all, const uint8_t* mask, hipStream_t st);
+                               const uint8_t* done, int done_all, const uint8_t* mask, float* carry, hipStream_t st);
 hipError_t launch_replay_sample(const RisVecReplay& rb, long long max_mem, int batch, const int64_t* idx, uint64_t seed,
                                 uint32_t counter, float* states, float* actions, float* rewards_g, float* rewards_l,
                                 float* states_, uint8_t* dones, float* masks, int64_t* idx_out, hipStream_t st);

@@ -93,8 +93,55 @@ class VecReplayBuffer:
             mk = (mk != 0).to(torch.uint8).reshape(n, L * L).contiguous() if mk.dtype != torch.uint8 \
                 else mk.reshape(n, L * L).contiguous()
         N.check(N.load().risvec_replay_store(C.byref(self._c), self.mem_cntr, n, _ptr(st), _ptr(ac), _ptr(rg), int(stride),
-                                             _ptr(rl), _ptr(st2), _ptr(dn), done_all, _ptr(mk), self._stream()))
+                                             _ptr(rl), _ptr(st2), _ptr(dn), done_all, _ptr(mk), None, self._stream()))
         self.mem_cntr += n
+
+    def bind_store(self, state: Optional[torch.Tensor], action: torch.Tensor, reward_g: torch.Tensor,
+                   reward_l: torch.Tensor, state_: torch.Tensor, mask: Optional[torch.Tensor] = None):
+        """`store_batch` with the arguments validated and marshalled once: returns `launch(done=False,
+        use_mask=True)`, one pre-built C-ABI call that appends the CURRENT contents of the given
+        tensors (they are read in place every call: the env's obs / reward / metrics, the marshalled
+        action rows, the NOMA mask).  All tensors must be contiguous float32 (mask uint8) on the device;
+        reward_g may be the env's [E, k] metrics tensor (column 0 is read).
+        `state=None`: the buffer carries the previous step's `state_` forward itself (the store kernel
+        drops a copy of `state_` into a ping-pong buffer while it has it in registers), i.e. the
+        driver's `marl_state_old_all = marl_state_new_all` (TRAIN:1277, 1774) without a copy kernel;
+        the first call then stores the CURRENT `state_` as `state`."""
+        n = int(state_.shape[0])
+        carry = None
+        if state is None:
+            carry = [state_.detach().clone().reshape(n, -1), torch.empty_like(state_).reshape(n, -1)]
+            state = carry[0]
+        S, A, L = self.input_shape * self.n_agents, self.n_actions * self.n_agents, self.n_agents
+
+        def ok(t, numel, dt=torch.float32):
+            return t.dtype == dt and t.device == self.device and t.is_contiguous() and t.numel() == numel
+        if not (ok(state, n * S) and ok(state_, n * S) and ok(action, n * A) and ok(reward_l, n * L)):
+            raise ValueError("bind_store: state/action/reward_l/state_ must be contiguous float32 tensors of n rows on %s"
+                             % self.device)
+        if reward_g.dtype != torch.float32 or reward_g.device != self.device or reward_g.shape[0] != n:
+            raise ValueError("bind_store: reward_g must be a float32 tensor with n rows on %s" % self.device)
+        stride = int(reward_g.stride(0)) if reward_g.dim() == 2 else 1
+        if mask is not None and not ok(mask, n * L * L, torch.uint8):
+            raise ValueError("bind_store: mask must be a contiguous uint8 [n, A, A] tensor")
+        fn, check, rb = N.load().risvec_replay_store, N.check, C.byref(self._c)
+        ptrs = (state.data_ptr(), action.data_ptr(), reward_g.data_ptr(), stride, reward_l.data_ptr(), state_.data_ptr())
+        mp, stream = _ptr(mask), self._stream()
+
+        flip = [0]
+
+        def launch(done: bool = False, use_mask: bool = True) -> None:
+            if carry is None:
+                src, dst = ptrs[0], None
+            else:
+                src, dst = carry[flip[0]].data_ptr(), carry[flip[0] ^ 1].data_ptr()
+                flip[0] ^= 1
+            check(fn(rb, self.mem_cntr, n, src, ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5], None,
+                     1 if done else 0, mp if use_mask else None, dst, stream))
+            self.mem_cntr += n
+
+        launch.keepalive = (state, action, reward_g, reward_l, state_, mask, carry)
+        return launch
 
     def store_transition(self, state, action, reward_g, reward_l, state_, done, mask_flat) -> None:
         """BUF:16-25 with the reference's signature (one transition; NumPy arrays or tensors)."""
@@ -136,11 +183,13 @@ class VecReplayBuffer:
 
 
 def marshal_actions(power_raw: torch.Tensor, probs: Optional[torch.Tensor], cpu_share_floor: float = 0.10,
-                    want_store: bool = True) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+                    want_store: bool = True, out: Optional[tuple] = None
+                    ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """Policy outputs of all agents of all envs -> (action_env [E,2,V], p_off01 [E,V], action_store
     [E, V*(V+2)] or None): TRAIN:1601-1608 (env action), TRAIN:1391-1396 (pairing power) and
     TRAIN:1386-1390 + 1776-1784 (replay action row = per agent [probs_i with zero diagonal, raw
-    power_i]).  power_raw [E,V,2] float32 in [-1,1]; probs [E,V,V] float32."""
+    power_i]).  power_raw [E,V,2] float32 in [-1,1]; probs [E,V,V] float32.  `out` = preallocated
+    (action_env, p_off01, action_store) to write into."""
     N.load()
     if power_raw.device.type != "cuda":
         raise RuntimeError("ris_vec_marl_amd needs a HIP device; there is no CPU fallback")
@@ -154,9 +203,16 @@ def marshal_actions(power_raw: torch.Tensor, probs: Optional[torch.Tensor], cpu_
             raise ValueError("probs must have shape [E, V, V]")
         pb = probs.to(pr.device, torch.float32).contiguous()
     dev = pr.device
-    action_env = torch.empty(E, 2, V, device=dev)
-    p01 = torch.empty(E, V, device=dev)
-    store = torch.empty(E, V * (V + 2), device=dev) if want_store else None
+    if out is not None:             # preallocated (action_env, p_off01, action_store): stable pointers for bound launches
+        action_env, p01, store = out
+        for t, shape in ((action_env, (E, 2, V)), (p01, (E, V))) + (((store, (E, V * (V + 2))),) if want_store else ()):
+            if t.dtype != torch.float32 or t.device != dev or not t.is_contiguous() or tuple(t.shape) != shape:
+                raise ValueError("marshal_actions: out tensors must be contiguous float32 of shapes "
+                                 "[E,2,V], [E,V], [E,V*(V+2)] on %s" % dev)
+    else:
+        action_env = torch.empty(E, 2, V, device=dev)
+        p01 = torch.empty(E, V, device=dev)
+        store = torch.empty(E, V * (V + 2), device=dev) if want_store else None
     N.check(N.load().risvec_marshal_actions(E, V, pr.data_ptr(), _ptr(pb), float(cpu_share_floor), action_env.data_ptr(),
                                             p01.data_ptr(), _ptr(store), torch.cuda.current_stream(dev).cuda_stream))
     return action_env, p01, store

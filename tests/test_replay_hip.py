@@ -111,3 +111,48 @@ def test_errors():
     z = torch.zeros(17, 20, device=DEV)
     with pytest.raises(ValueError):                            # a batch may not overwrite itself
         buf.store_batch(z, torch.zeros(17, 24, device=DEV), torch.zeros(17, device=DEV), torch.zeros(17, 4, device=DEV), z)
+
+
+@pytest.mark.parametrize("V", [6, 8, 3])
+def test_bound_store_with_carry_and_odd_shapes(V):
+    """bind_store(state=None): the buffer carries state_ forward itself (ping-pong copy made inside
+    the store kernel).  V = 6 / 3 take the scalar (non-float4) copy path; wraps included."""
+    from ris_vec_marl_amd import VecReplayBuffer
+    E, cap = 1000, 3500
+    rng = np.random.default_rng(V)
+    buf = VecReplayBuffer(cap, 5, V + 2, V, device=DEV)
+    orc = RO.ReplayOracle(cap, 5, V + 2, V)
+    obs = T(rng.normal(size=(E, V, 5)).astype(np.float32))
+    action = T(rng.normal(size=(E, V * (V + 2))).astype(np.float32))
+    metrics = T(rng.normal(size=(E, 16)).astype(np.float32))
+    reward = T(rng.normal(size=(E, V)).astype(np.float32))
+    mask = T((rng.uniform(size=(E, V, V)) < 0.5).astype(np.uint8))
+    store = buf.bind_store(None, action, metrics, reward, obs, mask)
+    prev = obs.cpu().numpy().reshape(E, -1).copy()
+    for t in range(5):
+        for x in (obs, action, metrics, reward):
+            x.copy_(T(rng.normal(size=tuple(x.shape)).astype(np.float32)))
+        use_mask = t % 2 == 0
+        store(done=t == 4, use_mask=use_mask)
+        cur = obs.cpu().numpy().reshape(E, -1)
+        orc.store_batch(prev, action.cpu().numpy(), metrics[:, 0].cpu().numpy(), reward.cpu().numpy(), cur, t == 4,
+                        mask.cpu().numpy().reshape(E, -1).astype(np.float32) if use_mask else None)
+        prev = cur.copy()
+    assert buf.mem_cntr == orc.mem_cntr
+    for k in ARRAYS:
+        assert np.array_equal(getattr(buf, k).cpu().numpy(), getattr(orc, k)), k
+
+
+@pytest.mark.parametrize("V", [5, 6, 16])
+def test_marshal_vs_oracle_other_shapes(V):
+    """Odd V takes the word-per-lane kernel, even V the row-per-lane one."""
+    from ris_vec_marl_amd import marshal_actions
+    rng = np.random.default_rng(V)
+    E = 777
+    power = rng.uniform(-1.2, 1.2, (E, V, 2)).astype(np.float32)
+    probs = rng.dirichlet(np.ones(V), (E, V)).astype(np.float32)
+    env_a, p01, store = marshal_actions(T(power), T(probs), 0.1)
+    a_o, p_o, s_o = RO.marshal_actions(power, probs, 0.1)
+    assert np.array_equal(env_a.cpu().numpy(), a_o.astype(np.float32))
+    assert np.array_equal(p01.cpu().numpy(), p_o.astype(np.float32))
+    assert np.array_equal(store.cpu().numpy(), s_o)

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Full end-of-round GPU session: gpu_round.sh (tests, smoke, bench, kernel trace, PMC passes) plus the
+# per-kernel table, the NOMA timings and the other BASELINE configs.  Usage: bash tools/gpu_full.sh <tag>
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out
+cd $R
+bash tools/gpu_round.sh $TAG pmc || exit 1
+echo "== every kernel at the C3 and C5 shapes" | tee -a $OUT/round_$TAG.log
+cd /tmp && export TMPDIR=/tmp
+for SHAPE in "32768 8 64" "32768 16 256"; do
+  N=$(echo $SHAPE | tr ' ' '_')
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/allk_${TAG}_$N -o trace -- python3 $R/tools/profile_all_kernels.py $SHAPE 10 > $OUT/allk_${TAG}_$N.json 2> $OUT/allk_${TAG}_$N.err
+  echo "allk $SHAPE rc=$?" | tee -a $OUT/round_$TAG.log
+  tail -1 $OUT/allk_${TAG}_$N.json > $OUT/allk_${TAG}_${N}_meta.json
+  python3 $R/tools/kernel_table.py $(find $OUT/allk_${TAG}_$N -name "*kernel_stats.csv" | head -1) $OUT/allk_${TAG}_${N}_meta.json | tee $OUT/allk_${TAG}_$N.md
+done
+cd $R
+echo "== NOMA grouping timings" | tee -a $OUT/round_$TAG.log
+timeout -k 10 300 python tools/profile_noma.py 32768 8 > $OUT/noma_${TAG}_8.json 2>/dev/null; cat $OUT/noma_${TAG}_8.json
+timeout -k 10 300 python tools/profile_noma.py 32768 16 10 > $OUT/noma_${TAG}_16.json 2>/dev/null; cat $OUT/noma_${TAG}_16.json
+echo "== other configs" | tee -a $OUT/round_$TAG.log
+b() { NAME=$1; shift; timeout -k 10 400 python bench.py --no-cpu-baseline "$@" > $OUT/bench_${TAG}_$NAME.json 2>/dev/null; python3 -c "import json,sys; d=json.load(open('$OUT/bench_${TAG}_$NAME.json')); print('$NAME: %.3e env-steps/s  %.1f us/step  frac %.3f' % (d['value'], d['ms_per_step']*1e3, d['roofline']['frac']))"; }
+b c2 --envs-per-gpu 4096 --ris 36
+b c4shard --envs-per-gpu 8192
+b big --envs-per-gpu 262144 --steps 300 --warmup 30
+b c5 --veh 16 --ris 256 --mode bcd --steps 300 --warmup 30
+b cached --mode cached
+b noma --noma
+b cached_noma --mode cached --noma
+find $OUT -name "*.db" -delete
+find $OUT -name "*kernel_trace.csv" -size +5M -delete
+exit 0

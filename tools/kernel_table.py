@@ -8,7 +8,7 @@ stats, meta = sys.argv[1], json.load(open(sys.argv[2]))
 B = meta["algorithmic_bytes"]
 rows = []
 for r in csv.DictReader(open(stats)):
-    name = r["Name"]
+    name = r["Name"].replace("(anonymous namespace)::", "")
     key = next((k for k in sorted(B, key=len, reverse=True) if k in name), None)
     if "k_step_fused_pipe" in name:      # one pipeline, three cores: price each against its own bytes
         key = "k_sarl_step" if "SarlCore" in name else "k_gain" if "GainCore" in name else "k_step_fused"

@@ -12,7 +12,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ris_vec_marl_amd import VecEnviron, reference_lanes, apply_yaml_config  # noqa: E402
+from ris_vec_marl_amd import (VecEnviron, reference_lanes, apply_yaml_config, NomaGrouper, VecReplayBuffer,  # noqa: E402
+                              marshal_actions)
 
 E, V, M, reps = (int(x) for x in (sys.argv[1:5] + ["32768", "8", "64", "20"][len(sys.argv) - 1:]))
 L = reference_lanes()
@@ -25,6 +26,10 @@ partner = torch.full((E, V), -1, dtype=torch.int32).cuda()
 ng = torch.full((E,), V, dtype=torch.int32).cuda()
 phase = torch.from_numpy(rng.uniform(0, 6.28, (E, M)).astype(np.float32)).cuda()
 pw = action[:, 0, :].contiguous()
+grouper = NomaGrouper(env) if V <= 16 else None
+replay = VecReplayBuffer(3 * E, 5, V + 2, V, device="cuda:0")
+power_raw = torch.from_numpy(rng.uniform(-1, 1, (E, V, 2)).astype(np.float32)).cuda()
+probs = torch.from_numpy(rng.dirichlet(np.ones(V), (E, V)).astype(np.float32)).cuda()
 for _ in range(reps):
     env.make_new_game()
     env.renew_positions()
@@ -40,11 +45,29 @@ for _ in range(reps):
     env.channel_model = "3gpp_umi"
     env.update_channel_gains()
     env.channel_model = "free"
+    env.update_channel_gains()
+    a_env, p01, a_store = marshal_actions(power_raw, probs, 0.1)      # k_marshal_actions
+    mask = None
+    if grouper is not None:
+        grouper.begin_episode(0)
+        mask = grouper.refresh_mask()                                   # k_noma_mask
+        grouper.group(p01, 0)                                          # k_noma_pre + k_noma_solve (all envs solve)
+        grouper.group(p01, 2)                                          # frozen step
+        grouper.flush()                                                # k_noma_flush
+    obs = env.tensors["obs"]
+    replay.store_batch(obs, a_store, env.tensors["metrics"], env.tensors["reward"], obs, False, mask)   # k_replay_store
+    replay.sample_buffer(4096)                                         # k_replay_sample
 torch.cuda.synchronize()
 B = dict(
     k_reset=E * V * (16 + 4 + 4 + 4), k_mobility=E * V * (16 + 4 + 4 + 16 + 4), k_geometry=E * V * (16 + 12 + 8 * M),
     k_colsum=E * (8 * V * M + 16 * M), k_random_phase=E * 8 * M, k_set_phase=E * 12 * M,
     k_bcd_sweep=E * (2 * 16 * M + 2 * 8 * M + 8 * M), k_gain=E * (8 * V * M + 8 * M + 8 * V),
     k_data_rate=E * 16 * V + 4 * E, k_step=E * (60 * V + 68), k_step_fused=E * (8 * V * M + 8 * M + 64 * V + 68),
-    k_sarl_step=E * (8 * V * M + 8 * M + 48 * V + 4), k_gain_3gpp=E * V * 20)
+    k_sarl_step=E * (8 * V * M + 8 * M + 48 * V + 4), k_gain_3gpp=E * V * 20,
+    # f2 / f3 (float words read + written; the NOMA kernels are latency-bound, bytes listed for completeness)
+    k_replay_store=E * (2 * 4 * (2 * 5 * V + V * (V + 2) + V + 1) + 5 * V * V + 1),
+    k_replay_sample=4096 * (2 * 4 * (2 * 5 * V + V * (V + 2) + V + 1 + V * V) + 2 + 8),
+    k_marshal_actions=E * (V * (8 + 4 * V) + 12 * V + 4 * V * (V + 2)),
+    k_noma_mask=E * (4 * V + V * V + 8), k_noma_pre=E * 40, k_noma_solve=E * (8 * V + 4 * V * V * 2 + V * V + 16 * V),
+    k_noma_flush=E * (8 * V * V + 8 * V + 4))
 print(json.dumps(dict(E=E, V=V, M=M, reps=reps, algorithmic_bytes=B)))
