@@ -67,6 +67,11 @@ def test_helpers(path):
         assert np.array_equal(S, d["S"][c])
         pairs = NO.mwm_primary(S, mask, float(d["accept_q"][c]), True)
         assert pairs == groups_of(d["mwm_partner"][c]), c
+        pairs_ns = NO.mwm_primary(S, mask, float(d["accept_q"][c]), False)       # allow_singles=False quirks
+        assert pairs_ns == groups_of(d["mwm_nosingles_partner"][c]), c
+        prm2 = NO.NomaParams(score_w_delta_db=0.7, score_w_history=0.45, abs_gain_min_db=float(d["abs_min"][c]),
+                             qos_soft_penalty_dbscore=2.5)
+        assert np.array_equal(NO.score_matrix(gdb12, mask, d["hist"][c], prm2, qos_in), d["S_absmin"][c]), c
         comp = NO.mwm_completion(S, mask, pairs, int(d["min_pairs"][c]), 0.30)
         assert sorted(comp) == groups_of(d["comp_partner"][c]), c
         assert len(comp) == d["comp_npairs"][c]

@@ -137,7 +137,8 @@ def capture_helpers(tag, N, seed, n_cases=96):
     ns = base_namespace(make_config(N))
     rec = {k: [] for k in ("gain", "gdb15", "gdb12", "q", "K", "tau", "mask", "hist", "qos", "S", "accept_q",
                            "mwm_partner", "mwm_npairs", "comp_partner", "comp_npairs", "min_pairs", "relax_tau",
-                           "relax_topk", "relax_mask", "row_tie", "topk_tie", "S_relaxed", "p01", "qos_ok")}
+                           "relax_topk", "relax_mask", "row_tie", "topk_tie", "S_relaxed", "p01", "qos_ok",
+                           "mwm_nosingles_partner", "mwm_nosingles_npairs", "abs_min", "S_absmin")}
     for c in range(n_cases):
         g = draw_gains(rng, N, ("wide", "strong", "weak")[c % 3])
         q = float(rng.uniform(0.05, 0.6))
@@ -167,6 +168,11 @@ def capture_helpers(tag, N, seed, n_cases=96):
                                                       qos_soft_mask=qos if use_qos else None, qos_soft_penalty=6.0)
         accept_q = float(rng.choice([0.05, 0.10, 0.2, 0.5, 1.0]))
         pairs = ns["_mwm_primary"](S=S, feasible=mask, accept_quantile=accept_q, allow_singles=True)
+        pairs_ns = ns["_mwm_primary"](S=S, feasible=mask, accept_quantile=accept_q, allow_singles=False)
+        abs_min = float(np.quantile(gdb12, min(1.0, rng.uniform(0.2, 1.1)) if c % 3 else 0.5)) if c % 7 else 0.0
+        S_abs = ns["_score_matrix_from_gain_and_history"](gain_linear=g, feasible_mask=mask, hist_affinity=hist,
+                                                          w_delta_db=0.7, w_hist=0.45, abs_gain_min_db=abs_min,
+                                                          qos_soft_mask=qos if use_qos else None, qos_soft_penalty=2.5)
         min_pairs = int(rng.integers(1, N // 2 + 1))
         comp = ns["_mwm_completion"](S, mask, [tuple(p) for p in pairs], min_pairs)
         rtau = float(rng.uniform(2.0, 12.0))
@@ -183,7 +189,8 @@ def capture_helpers(tag, N, seed, n_cases=96):
                          mwm_partner=partner_of(grp(pairs), N), mwm_npairs=len(pairs),
                          comp_partner=partner_of(grp(comp), N), comp_npairs=len(comp), min_pairs=min_pairs,
                          relax_tau=rtau, relax_topk=rtop, relax_mask=rel, row_tie=row_tie, topk_tie=topk_tie,
-                         S_relaxed=S2, p01=p01, qos_ok=qos).items():
+                         S_relaxed=S2, p01=p01, qos_ok=qos, mwm_nosingles_partner=partner_of(grp(pairs_ns), N),
+                         mwm_nosingles_npairs=len(pairs_ns), abs_min=abs_min, S_absmin=S_abs).items():
             rec[k].append(v)
     np.savez_compressed(os.path.join(OUT_DIR, "noma_helpers_%s.npz" % tag), N=N, noise_power=noise, P_max=Pmax,
                         R_min=Rmin, **{k: np.asarray(v) for k, v in rec.items()})
