@@ -68,7 +68,6 @@ __device__ __forceinline__ int wave_sum(int x) {
     return x;
 }
 __device__ __forceinline__ bool finite(double x) { return fabs(x) < kInf; }
-__device__ __forceinline__ bool is_first(int p) { return p >= 0 && p < 65536; }
 __device__ __forceinline__ bool paired_with(int p, int j) { return p >= 0 && (p & 0xFFFF) == j; }
 
 // One deferred frozen step on a history entry / a streak (TRAIN:1406, 1556-1561).

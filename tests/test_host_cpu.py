@@ -13,6 +13,7 @@ import torch
 import ris_vec_marl_amd as rv
 from ris_vec_marl_amd import _native as N
 from oracle import risvec_oracle as orc
+from oracle import noma_oracle as orc_noma
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_YAML_EFFECTIVE = dict(w_d=1.0, w_e=1.0, rate=1.0, f_local_max=3.0e9, cycles_per_bit=300.0, bandwidth=5.0,
@@ -193,3 +194,57 @@ def test_shard_range():
         assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
     with pytest.raises(ValueError):
         rv.dist.shard_range(8, 8, 8)
+
+
+def test_noma_and_replay_abi_without_a_gpu():
+    """f2 / f3 entry points: struct layouts agree between ctypes and the library (the C defaults land
+    in the right Python fields), and bad arguments are rejected before anything is launched."""
+    lib = N.load()
+    for V in (4, 8, 16):
+        p = N.RisVecNomaParams()
+        lib.risvec_noma_default_params(C.byref(p), V)
+        q = rv.NomaConfig(V).to_c(noise_power=10 ** (-174 / 10) / 1000 * 1e6, P_max=1.0)
+        for name, _ in N.RisVecNomaParams._fields_:
+            a, b = getattr(p, name), getattr(q, name)
+            assert a == pytest.approx(b, rel=1e-6) or (a == b), (V, name, a, b)
+    ns = N.RisVecNomaState()
+    p = rv.NomaConfig(8).to_c(1e-14, 1.0)
+    assert lib.risvec_noma_begin_episode(None, None) == N.ERR_ARG
+    ns.n_envs, ns.n_veh = 4, 17
+    assert lib.risvec_noma_mask(C.byref(ns), None, None, 0.5, 3, None) == N.ERR_SHAPE
+    assert b"n_veh" in lib.risvec_last_error()
+    ns.n_veh = 8
+    assert lib.risvec_noma_mask(C.byref(ns), None, None, 0.5, 3, None) == N.ERR_ARG        # NULL gain
+    assert lib.risvec_noma_group(C.byref(ns), C.byref(p), None, None, None, 0, 3, None, None, 1, 0, None, 0, 0, None,
+                                 None) == N.ERR_ARG
+    assert lib.risvec_noma_flush(C.byref(ns), None, None) == N.ERR_ARG
+    rb = N.RisVecReplay()
+    assert lib.risvec_replay_store(C.byref(rb), 0, 1, None, None, None, 1, None, None, None, 0, None, None, None) \
+        == N.ERR_SHAPE
+    rb.n_agents, rb.input_shape, rb.n_actions, rb.mem_size = 8, 5, 10, 100
+    assert lib.risvec_replay_store(C.byref(rb), 0, 1, None, None, None, 1, None, None, None, 0, None, None, None) \
+        == N.ERR_ARG
+    assert lib.risvec_replay_sample(C.byref(rb), 0, 4, None, 0, 0, None, None, None, None, None, None, None, None,
+                                    None) == N.ERR_ARG
+    assert lib.risvec_marshal_actions(0, 8, None, None, 0.1, None, None, None, None) == N.ERR_SHAPE
+    assert lib.risvec_marshal_actions(4, 8, None, None, 0.1, None, None, None, None) == N.ERR_ARG
+    with pytest.raises(NotImplementedError):
+        c = rv.NomaConfig(8); c.use_mwm_primary = False; c.to_c(1e-14, 1.0)
+
+
+def test_noma_config_reads_the_drivers_yaml_keys():
+    """NomaConfig.apply_yaml takes the same keys from the same places as marl_train_bcd.py:575,
+    639-660, 716-741; values below are the shipped config.yaml's (its lines 39-44, 53, 78-83, 116-120, 144-148)."""
+    y = {"min_pair_target": 3, "use_mwm_primary": True, "mwm_accept_quantile": 0.10, "mwm_backoff_rounds": 3,
+         "mwm_accept_q_step": 0.05, "qos_enable": True, "freeze_group_in_episode": True, "freeze_recalc_every": 0,
+         "freeze_unstick_prob": 0.0, "freeze_reward_drop_ratio": 0.05,
+         "reward": {"mask_enable": True, "mask_topk_start": 7, "mask_topk_end": 7, "mask_tau_q_start": 0.10,
+                    "mask_tau_q_end": 0.25, "pairing_threshold_quantile": 0.25}}
+    c = rv.NomaConfig(8).apply_yaml(y)
+    o = orc_noma.NomaParams.yaml_effective(8)
+    for k in ("min_pair_target", "mwm_accept_quantile", "mwm_backoff_rounds", "mwm_accept_q_step", "qos_enable",
+              "qos_R_min_bpsHz", "mask_topk_start", "mask_topk_end", "mask_tau_q_start", "mask_tau_q_end",
+              "pairing_threshold_quantile", "freeze_group_in_episode", "freeze_recalc_every"):
+        assert getattr(c, k) == getattr(o, k), k
+    assert c.mask_schedule(50) == orc_noma.mask_schedule(o, 50, 8)
+    assert rv.anneal_topk(37, 8, 7, 4, 200) == orc_noma.anneal_topk(37, 8, 7, 4, 200)
