@@ -344,7 +344,6 @@ typedef struct RisVecNomaState {
     uint8_t *mask;                  /* [E,N,N] last_mask_mat (0/1)                          */
     double *tau;                    /* [E]     last_tau_now                                 */
     int32_t *pending;               /* [E]     frozen steps not yet applied to hist / streak */
-    int32_t *todo;                  /* [E+2]   work list of one group() call + 2 control words; zero it once at allocation */
 } RisVecNomaState;
 
 void risvec_noma_default_params(RisVecNomaParams *p, int32_t n_veh);   /* driver Config defaults */

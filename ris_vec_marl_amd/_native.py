@@ -96,7 +96,7 @@ class RisVecNomaState(C.Structure):
     _fields_ = [
         ("n_envs", C.c_int32), ("n_veh", C.c_int32), ("env_offset", C.c_int64),
         ("hist", _FP), ("streak", _FP), ("partner", _FP), ("n_groups", _FP), ("last_global", _FP),
-        ("best_global", _FP), ("flags", _FP), ("mask", _FP), ("tau", _FP), ("pending", _FP), ("todo", _FP),
+        ("best_global", _FP), ("flags", _FP), ("mask", _FP), ("tau", _FP), ("pending", _FP),
     ]
 
 

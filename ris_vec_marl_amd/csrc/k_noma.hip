@@ -5,14 +5,15 @@
 // check (TRAIN:858-880) and the control logic with the freeze-in-episode safeties
 // (TRAIN:1401-1562, 1618-1623).
 //
-// Three kernels per group() call, because almost every step of an episode is a FROZEN step:
-//   k_noma_pre    one lane per env: reward bookkeeping (TRAIN:1618-1623), the freeze decision
-//                 (TRAIN:1527-1540); frozen envs only bump `pending` (their history decay / pair
-//                 increments and streak updates are replayed, operation for operation, the next time
-//                 somebody needs them), the others are appended to a compact to-do list;
-//   k_noma_solve  ONE WAVEFRONT PER LISTED ENV (workgroup = 64 lanes): replay, then the pairing;
-//   k_noma_flush  materialises `pending` for readers of the history / streak tensors.
-// In the solve kernel the N x N matrices (N <= 16) live in LDS with the entries dealt round-robin to
+// Almost every step of an episode is a FROZEN step, so k_noma_group (one launch per group() call) is
+// built around that: a wavefront owns 8 consecutive envs; 8 lanes first do the per-env bookkeeping
+// (reward tracking TRAIN:1618-1623, the freeze decision TRAIN:1527-1540); frozen envs only bump
+// `pending` -- the history decay / pair increments and streak updates they owe are replayed,
+// operation for operation, the next time somebody needs them (k_noma_flush for readers of those
+// tensors) -- and the wavefront then solves, ONE ENV AT A TIME WITH ALL 64 LANES, the envs that
+// asked for it.  A frozen step is a single short launch; when every env re-solves there are E/8
+// wavefronts with 8 solves each, which still fills the chip.
+// In a solve the N x N matrices (N <= 16) live in LDS with the entries dealt round-robin to
 // the lanes; every decision the reference takes by comparing float64 numbers is taken by comparing
 // float64 numbers formed in the same association order (fp contraction is off for the whole file:
 // the matcher's exact ties are decided by last-bit rounding).
@@ -80,10 +81,11 @@ __device__ __forceinline__ float replay_hist(float h, int pending, float decay, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// pre: one lane per env
+// bookkeeping of one env (run by one lane)
 // ---------------------------------------------------------------------------------------------
-// The per-env part of k_noma_pre; returns true when the env has to (re)solve its pairing.
-__device__ __forceinline__ bool noma_pre_env(const NomaArgs& A, int env) {
+// Per-env bookkeeping + freeze decision; returns true when the env has to (re)solve its pairing
+// (`flags_out` = its updated flag bits, handed to the solving wavefront through a shuffle).
+__device__ __forceinline__ bool noma_pre_env(const NomaArgs& A, int env, int& flags_out) {
     const RisVecNomaParams& P = A.P;
     int flags = A.ns.flags[env];
     double last = A.ns.last_global[env], best = A.ns.best_global[env];
@@ -114,6 +116,7 @@ __device__ __forceinline__ bool noma_pre_env(const NomaArgs& A, int env) {
         }
     }
     A.ns.flags[env] = (uint8_t)flags;
+    flags_out = flags;
     if (frozen && !need_repair) {                      // reuse episode_groups (TRAIN:1542-1547): defer the bookkeeping
         A.ns.pending[env] += 1;
         if (A.info_out) {
@@ -125,23 +128,6 @@ __device__ __forceinline__ bool noma_pre_env(const NomaArgs& A, int env) {
     return true;
 }
 
-
-__global__ void __launch_bounds__(kBlock)
-k_noma_pre(NomaArgs A) {
-    const int env = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = env < A.ns.n_envs;
-    bool solve = false;
-    if (live) solve = noma_pre_env(A, env);
-    // append to the to-do list: one atomic per wavefront, not per env (on the first steps of an
-    // episode every env re-solves and 32 768 atomics on one word would dominate this kernel)
-    const unsigned long long m = __ballot(solve);
-    if (m == 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(A.ns.todo + A.ns.n_envs, __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1, kWave);
-    if (solve) A.ns.todo[base + __popcll(m & ((1ull << lane) - 1))] = env;
-}
 
 // ---------------------------------------------------------------------------------------------
 // flush: materialise the deferred frozen steps (one lane per matrix entry)
@@ -168,7 +154,7 @@ k_noma_clear_pending(RisVecNomaState ns) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// solve: one wavefront per env of the to-do list
+// group: a wavefront per 8 envs -- bookkeeping by 8 lanes, then one full-wave solve per env that needs it
 // ---------------------------------------------------------------------------------------------
 template <int NMAX>
 struct Shape {
@@ -241,8 +227,9 @@ __device__ __forceinline__ double quantile_linear(const Ranks<EPL>& R, double q)
 struct MatchTab {
     const double* dp;
     const int* base;       // [K+1]
-    const int* binom;      // [16][kBinW]
     const int* sizeoff;    // [16][kBinW + 1]
+    const uint16_t* clo;   // [256]      colex rank of the low 8 bits of T
+    const uint16_t* chi;   // [9][128]   colex rank contribution of bits 8.. of T, given popcount(low 8)
     int K, full;
     bool plain;            // 2^K fits the table: slot = mask (no ranking arithmetic on the critical path)
     __device__ __forceinline__ int slot(int mask) const {
@@ -250,9 +237,8 @@ struct MatchTab {
         const int x = __ffs(~mask) - 1;
         unsigned T = (unsigned)mask >> (x + 1);
         const int n = K - 1 - x;
-        int r = base[x] + sizeoff[n * (kBinW + 1) + __popc(T)];
-        for (int i = 1; T; ++i, T &= T - 1) r += binom[(__ffs(T) - 1) * kBinW + i];
-        return r;
+        const unsigned lo = T & 255u, hi = T >> 8;
+        return base[x] + sizeoff[n * (kBinW + 1) + __popc(T)] + clo[lo] + chi[__popc(lo) * 128 + hi];
     }
     __device__ __forceinline__ double value(int mask) const { return mask == full ? 0.0 : dp[slot(mask)]; }
 };
@@ -277,9 +263,15 @@ __device__ __forceinline__ double best_at(const MatchTab& M, const double* w, bo
     return best;
 }
 
+// Envs per wavefront: as many wavefronts as the chip keeps resident when every env solves (8 users: ~20
+// wavefronts per CU fit -> 8 envs each at 32 768 envs; 16 users: the 32 KB of LDS allow ~4 per CU -> 32
+// envs each), so a frozen step launches no more blocks than that.
+template <int NMAX> struct EnvsPerWave { static constexpr int value = NMAX <= 8 ? 8 : 32; };
+
 template <int NMAX>
-__global__ void __launch_bounds__(kWave)
-k_noma_solve(NomaArgs A) {
+__global__ void __launch_bounds__(kWave, NMAX <= 8 ? 5 : 1)
+k_noma_group(NomaArgs A) {
+    constexpr int kEnvsPerWave = EnvsPerWave<NMAX>::value;
     using S = Shape<NMAX>;
     constexpr int EPL = S::EPL;
     __shared__ double s_S[S::NN], s_R[S::NN], s_W[S::NN], s_w[kNV * kNV], s_g[kNV], s_lin[kNV], s_p[kNV];
@@ -288,14 +280,24 @@ k_noma_solve(NomaArgs A) {
     __shared__ uint8_t s_feas[S::NN], s_qos[S::NN];
     __shared__ int s_part[kNV], s_base[kNV + 1], s_binom[16 * kBinW], s_sizeoff[16 * (kBinW + 1)];
     __shared__ signed char s_arg[S::DP];               // choice taken at each state, for the walk-back
+    constexpr bool kRanked = NMAX > S::KPLAIN;         // more users than the plain 2^K table can hold?
+    __shared__ uint16_t s_clo[kRanked ? 256 : 1], s_chi[kRanked ? 9 * 128 : 1];   // colex-rank lookup
     const int lane = threadIdx.x;
     const int N = A.ns.n_veh, NN = N * N;
     const RisVecNomaParams& P = A.P;
     const bool singles = P.mwm_allow_singles != 0;
 
-    // Most calls find an empty or short list (frozen steps): blocks without work skip straight to the exit.
-    const int n_todo = A.ns.todo[A.ns.n_envs];
-    if ((int)blockIdx.x < n_todo) {
+    int ei[EPL], ej[EPL];                              // this lane's matrix entries
+    bool ein[EPL];
+    bool tables_ready = false;
+    for (int e0 = blockIdx.x * kEnvsPerWave; e0 < A.ns.n_envs; e0 += gridDim.x * kEnvsPerWave) {
+    int my_flags = 0;
+    bool my_solve = false;
+    if (lane < kEnvsPerWave && e0 + lane < A.ns.n_envs) my_solve = noma_pre_env(A, e0 + lane, my_flags);
+    unsigned todo = (unsigned)__ballot(my_solve);
+    if (todo == 0) continue;                           // the common case: all 8 envs frozen
+    if (!tables_ready) {
+    tables_ready = true;
     // binomials C(c, i) and their prefix sums over i (Pascal rows; one row per lane)
     if (lane < 16) {
         int c = 1;                                     // C(lane, 0)
@@ -307,9 +309,6 @@ k_noma_solve(NomaArgs A) {
             c = i < lane ? c * (lane - i) / (i + 1) : 0;   // C(lane, i+1)
         }
     }
-    // this lane's matrix entries
-    int ei[EPL], ej[EPL];
-    bool ein[EPL];
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
         const int idx = lane + t * kWave;
@@ -317,10 +316,26 @@ k_noma_solve(NomaArgs A) {
         ei[t] = ein[t] ? idx / N : 0;
         ej[t] = ein[t] ? idx % N : 0;
     }
-    for (int item = blockIdx.x; item < n_todo; item += gridDim.x) {
-        const int env = A.ns.todo[item];
+    if constexpr (kRanked) {                           // ranked table index: only beyond 2^KPLAIN masks
+        __syncthreads();
+        for (int b = lane; b < 256; b += kWave) {      // sum over set bits c_1 < c_2 < ... of C(c_i, i)
+            int r = 0, i = 1;
+            for (unsigned m = b; m; m &= m - 1, ++i) r += i < kBinW ? s_binom[(__ffs(m) - 1) * kBinW + i] : 0;
+            s_clo[b] = (uint16_t)r;
+        }
+        for (int e = lane; e < 9 * 128; e += kWave) {  // bits 8.. (positions 8 + c), ranks continue at p + 1
+            const int p = e / 128;
+            int r = 0, i = p + 1;
+            for (unsigned m = e % 128; m; m &= m - 1, ++i) r += i < kBinW ? s_binom[(8 + __ffs(m) - 1) * kBinW + i] : 0;
+            s_chi[e] = (uint16_t)r;
+        }
+    }
+    }   // tables
+    for (; todo; todo &= todo - 1) {
+        const int slot = __ffs(todo) - 1;
+        const int env = e0 + slot;
         __syncthreads();                               // LDS reuse across envs
-        const int flags = A.ns.flags[env];
+        const int flags = __shfl(my_flags, slot, kWave);
         const int pend = A.ns.pending[env];
         const bool had_groups = (flags & RISVEC_NOMA_HAS_GROUPS) != 0;
         float* hist = A.ns.hist + (long long)env * NN;
@@ -442,7 +457,7 @@ k_noma_solve(NomaArgs A) {
                         s_base[K] = off;
                     }
                     __syncthreads();
-                    const MatchTab MT{s_dp, s_base, s_binom, s_sizeoff, K, (1 << K) - 1, K <= S::KPLAIN};
+                    const MatchTab MT{s_dp, s_base, s_sizeoff, s_clo, s_chi, K, (1 << K) - 1, K <= S::KPLAIN};
                     for (int x = K - 1; x >= 0; --x) {          // a state only needs states with a larger x
                         const int n = K - 1 - x, low = (1 << x) - 1;
                         for (int T = lane; T < (1 << n); T += kWave) {
@@ -560,17 +575,7 @@ k_noma_solve(NomaArgs A) {
             }
         }
     }
-    }   // blockIdx.x < n_todo
-    // every block has read the list length by the time it gets here: the last one to leave clears
-    // it for the next call (saves a memset launch on the frozen steps, which are launch-bound)
-    if (lane == 0) {
-        int* ctl = A.ns.todo + A.ns.n_envs;
-        __threadfence();
-        if (atomicAdd(ctl + 1, 1) == (int)gridDim.x - 1) {
-            ctl[0] = 0;
-            ctl[1] = 0;
-        }
-    }
+    }   // 8-env groups
 }
 
 // tau = quantile q of |g_strong - g_weak| (TRAIN:842-855) and the feasibility mask (TRAIN:134-156).
@@ -682,18 +687,12 @@ hipError_t launch_noma_group(const RisVecNomaState& ns, const RisVecNomaParams& 
                              hipStream_t st) {
     NomaArgs a{ns, p, gain, gdb12, p01, use_mask, K_back, tau_back, prev_global, prev_stride, i_step,
                u_unstick, seed, counter, info_out};
-    hipLaunchKernelGGL(k_noma_pre, dim3((ns.n_envs + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a);
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return err;
-    // The list length is only known on the device: a fixed grid walks it (blocks beyond it exit at
-    // once).  Steps on which most envs are expected to be frozen get a small grid -- an empty 4 096-block
-    // launch costs more than the whole frozen step otherwise; a wrong guess only costs speed.
-    const bool busy_step = !p.freeze_group_in_episode || i_step <= 1 ||
-                           (p.freeze_recalc_every > 0 && i_step % p.freeze_recalc_every == 0);
-    int grid = noma_grid(ns.n_envs);
-    if (!busy_step && grid > 128) grid = 128;
-    if (ns.n_veh <= 8) hipLaunchKernelGGL((k_noma_solve<8>), dim3(grid), dim3(kWave), 0, st, a);
-    else hipLaunchKernelGGL((k_noma_solve<16>), dim3(grid), dim3(kWave), 0, st, a);
+    const int epw = ns.n_veh <= 8 ? EnvsPerWave<8>::value : EnvsPerWave<16>::value;
+    long long waves = ((long long)ns.n_envs + epw - 1) / epw;
+    if (waves > (1 << 20)) waves = 1 << 20;            // grid-stride beyond that
+    const dim3 grid((unsigned)waves);
+    if (ns.n_veh <= 8) hipLaunchKernelGGL((k_noma_group<8>), grid, dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL((k_noma_group<16>), grid, dim3(kWave), 0, st, a);
     return hipGetLastError();
 }
 

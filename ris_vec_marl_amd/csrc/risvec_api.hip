@@ -355,7 +355,7 @@ static int check_noma_state(const char* fn, const RisVecNomaState* ns) {
     REQ_PTR(ns->hist, "noma.hist"); REQ_PTR(ns->streak, "noma.streak"); REQ_PTR(ns->partner, "noma.partner");
     REQ_PTR(ns->n_groups, "noma.n_groups"); REQ_PTR(ns->last_global, "noma.last_global");
     REQ_PTR(ns->best_global, "noma.best_global"); REQ_PTR(ns->flags, "noma.flags");
-    REQ_PTR(ns->pending, "noma.pending"); REQ_PTR(ns->todo, "noma.todo");
+    REQ_PTR(ns->pending, "noma.pending");
     return RISVEC_OK;
 }
 

@@ -185,12 +185,11 @@ class NomaGrouper:
         t["mask"] = z(E, V, V, dt=torch.uint8)
         t["tau"] = z(E, dt=torch.float64)
         t["pending"] = z(E, dt=torch.int32)
-        t["todo"] = z(E + 4, dt=torch.int32)
         t["info"] = z(E, 4, dt=torch.int32)
         s = N.RisVecNomaState()
         s.n_envs, s.n_veh, s.env_offset = E, V, int(getattr(self.env, "env_offset", 0))
         for k in ("hist", "streak", "partner", "n_groups", "last_global", "best_global", "flags", "mask", "tau",
-                  "pending", "todo"):
+                  "pending"):
             setattr(s, k, t[k].data_ptr())
         self._cstate = s
 

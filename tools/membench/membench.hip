@@ -1,0 +1,38 @@
+// Achievable-bandwidth yardstick for the roofline in DESIGN.md: the simplest possible streaming
+// kernels on the same device, same sizes as the headline kernel's working set.  Not part of the
+// product library.   read: every lane float4-loads a grid-strided stream and keeps a running sum
+// (one float written per lane at the end); mix: reads `n_read` float4s and writes `n_write`.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+__global__ void __launch_bounds__(256)
+k_read(const float4* __restrict__ src, long long n, float* __restrict__ sink) {
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float4 x0 = src[i], x1 = src[i + stride], x2 = src[i + 2 * stride], x3 = src[i + 3 * stride];
+        a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+        a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+        a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+        a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
+    }
+    for (; i < n; i += stride) { const float4 x = src[i]; a0.x += x.x; a0.y += x.y; a0.z += x.z; a0.w += x.w; }
+    sink[(long long)blockIdx.x * 256 + threadIdx.x] =
+        a0.x + a0.y + a0.z + a0.w + a1.x + a1.y + a1.z + a1.w + a2.x + a2.y + a2.z + a2.w + a3.x + a3.y + a3.z + a3.w;
+}
+
+__global__ void __launch_bounds__(256)
+k_copy(const float4* __restrict__ src, float4* __restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+extern "C" int membench_read(const void* src, long long n_float4, void* sink, int blocks, void* stream) {
+    hipLaunchKernelGGL(k_read, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)src, n_float4, (float*)sink);
+    return (int)hipGetLastError();
+}
+extern "C" int membench_copy(const void* src, void* dst, long long n_float4, int blocks, void* stream) {
+    hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n_float4);
+    return (int)hipGetLastError();
+}
