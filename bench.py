@@ -45,6 +45,8 @@ def algorithmic_bytes(V: int, M: int, mode: str = "fused") -> int:
         return 60 * V + 68
     if mode == "bcd":
         return 8 * V * M + 16 * M + 64 * V + 68
+    if mode == "sarl":      # + the agent's phase row read (4M) and theta written then read (8M + 8M); 48V + 4 of step I/O
+        return 8 * V * M + 20 * M + 48 * V + 4
     return 8 * V * M + 8 * M + 64 * V + 68
 
 
@@ -158,15 +160,17 @@ def main() -> None:
     ap.add_argument("--envs-per-gpu", type=int, default=32768)
     ap.add_argument("--veh", type=int, default=8)
     ap.add_argument("--ris", type=int, default=64)
-    ap.add_argument("--gather-every", type=int, default=8,
+    ap.add_argument("--gather-every", type=int, default=32,
                     help="N>1: all-gather the joint observation every k steps on a side stream (0 = never). "
                          "At 32 768 envs/GPU one gather moves 5.2 MB per rank over point-to-point xGMI links, "
-                         "several env steps' worth of time, so it is amortised rather than issued every step.")
+                         "several env steps' worth of time (an 8-GPU ring moves 7 x 5.2 MB into every GPU, ~0.2 ms), so "
+                         "it is amortised rather than issued every step; at 32 its duty cycle stays near 20 %%.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lean", action="store_true", help="experiment: skip metrics and obs writes")
-    ap.add_argument("--mode", default="fused", choices=["fused", "cached", "bcd"],
+    ap.add_argument("--mode", default="fused", choices=["fused", "cached", "bcd", "sarl"],
                     help="fused: gains+step each step (headline); cached: step only (reference cadence); "
-                         "bcd: BCD sweep + gains + step each step (BASELINE config 5)")
+                         "bcd: BCD sweep + gains + step each step (BASELINE config 5); "
+                         "sarl: the single-agent env variant's step (SURVEY 8 f1): phases from the agent + gains + step")
     ap.add_argument("--noma", action="store_true",
                     help="also run the NOMA grouping stage (SURVEY 8 f2) before every step, with the reference's "
                          "episode structure: 100-step episodes, mask rebuilt at step 0, groups frozen in between")
@@ -241,8 +245,14 @@ def main() -> None:
         store = replay.bind_store(None, a_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"],
                                   grouper.mask)
     group = grouper.bind_group(p_off01) if grouper is not None else None
-    launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full, power_w=False,
-                           obs=full)
+    if args.mode == "sarl":
+        from ris_vec_marl_amd.sarl import SarlParams
+        phase = torch.from_numpy(rng.uniform(0, 2 * np.pi, (E, M)).astype(np.float32)).to(device)
+        sp = SarlParams()
+        launch = lambda: env.sarl_step(action, phase, None, sp, obs=full)       # noqa: E731
+    else:
+        launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full, power_w=False,
+                               obs=full)
     episode_len = 100
 
     def one_step(i: int) -> None:
@@ -293,12 +303,12 @@ def main() -> None:
     per_env = algorithmic_bytes(V, M, args.mode)
     bytes_per_launch = per_env * E
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    kname = {"fused": "k_step_fused", "cached": "k_step<", "bcd": "k_bcd"}[args.mode]
+    kname = {"fused": "k_step_fused", "cached": "k_step<", "bcd": "k_bcd", "sarl": "SarlCore"}[args.mode]
     traffic, traffic_src = (None, None)
     if (E, V, M, args.mode) == (32768, 8, 64, "fused") and full:
         traffic, traffic_src = measured_traffic(kname)
     workload = {"fused": "RIS cascaded gains + step()", "cached": "step() on cached gains",
-                "bcd": "BCD sweep + gains + step()"}[args.mode]
+                "bcd": "BCD sweep + gains + step()", "sarl": "SARL get_next_phase + gains + step()"}[args.mode]
     out = {
         "metric": "env-steps/sec (all agents) at 8 veh x 64 RIS",
         "value": E * world * args.steps / dt,
@@ -324,7 +334,8 @@ def main() -> None:
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": {"fused": "k_step_fused_pipe<8,64,2,MarlCore>" if (V, M) == (8, 64) else "k_step_fused*",
-                                "cached": "k_step", "bcd": "k_bcd_lane + k_step_fused*"}[args.mode],
+                                "cached": "k_step", "bcd": "k_bcd_lane + k_step_fused*",
+                                "sarl": "k_set_phase + k_step_fused_pipe<..,SarlCore>"}[args.mode],
                      "algorithmic_bytes_per_env_step": per_env, "bytes_per_launch": bytes_per_launch,
                      "avg_launch_ms": kernel_ms},
     }

@@ -169,26 +169,28 @@ k_marshal_actions(int E, int V, const float* power_raw, const float* probs, floa
     }
 }
 
-// Even V: one lane per (env, agent) moves that agent's whole row with 8-byte accesses (probs row in,
-// [probs | power] row out: both start on 8-byte boundaries when V is even).
+// Even V: one lane per float2 of the replay action row [E, V, V+2] (8-byte accesses, fully coalesced
+// on the write side; the probs / power reads are contiguous per agent); the lane holding an agent's
+// power pair also writes that agent's env action and pairing power.
 __global__ void __launch_bounds__(kBlock)
-k_marshal_rows(int E, int V, const float* power_raw, const float* probs, float floor_eff, float* action_env,
-               float* p_off01, float* action_store) {
-    const unsigned ev = blockIdx.x * kBlock + threadIdx.x;
-    if (ev >= (unsigned)E * V) return;
+k_marshal_pairs(int E, int V, const float* power_raw, const float* probs, float floor_eff, float* action_env,
+                float* p_off01, float* action_store) {
+    const unsigned gid = blockIdx.x * kBlock + threadIdx.x;    // E*V*(V+2)/2 < 2^31 is checked by the API
+    const unsigned H = (unsigned)V / 2 + 1;                    // float2 per row
+    if (gid >= (unsigned)E * V * H) return;
+    const unsigned k2 = gid % H, ev = gid / H;
+    if (k2 < (unsigned)V / 2) {
+        if (!action_store) return;
+        const unsigned v = ev % V;
+        float2 p = *reinterpret_cast<const float2*>(probs + (size_t)ev * V + 2 * k2);
+        if (2 * k2 == v) p.x = 0.0f;                                   // np.fill_diagonal(., 0), TRAIN:1390
+        if (2 * k2 + 1 == v) p.y = 0.0f;
+        *reinterpret_cast<float2*>(action_store + (size_t)gid * 2) = p;
+        return;
+    }
     const unsigned v = ev % V, e = ev / V;
     const float2 pw = *reinterpret_cast<const float2*>(power_raw + (size_t)ev * 2);
-    if (action_store) {
-        const float2* src = reinterpret_cast<const float2*>(probs + (size_t)ev * V);
-        float2* dst = reinterpret_cast<float2*>(action_store + (size_t)ev * (V + 2));
-        for (unsigned k2 = 0; k2 < (unsigned)V / 2; ++k2) {
-            float2 p = src[k2];
-            if (2 * k2 == v) p.x = 0.0f;                               // np.fill_diagonal(., 0), TRAIN:1390
-            if (2 * k2 + 1 == v) p.y = 0.0f;
-            dst[k2] = p;
-        }
-        dst[V / 2] = pw;                                               // raw policy output, TRAIN:1777-1782
-    }
+    if (action_store) *reinterpret_cast<float2*>(action_store + (size_t)gid * 2) = pw;   // raw output, TRAIN:1777-1782
     const float m0 = (fminf(fmaxf(pw.x, -0.999f), 0.999f) + 1.0f) / 2.0f;       // TRAIN:1603-1605
     const float m1 = (fminf(fmaxf(pw.y, -0.999f), 0.999f) + 1.0f) / 2.0f;
     if (action_env) {
@@ -229,8 +231,8 @@ hipError_t launch_replay_sample(const RisVecReplay& rb, long long max_mem, int b
 hipError_t launch_marshal_actions(int E, int V, const float* power_raw, const float* probs, float floor_eff,
                                   float* action_env, float* p_off01, float* action_store, hipStream_t st) {
     if (V % 2 == 0) {
-        const long long rows = (long long)E * V;
-        hipLaunchKernelGGL(k_marshal_rows, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, E, V,
+        const long long pairs = (long long)E * V * (V / 2 + 1);
+        hipLaunchKernelGGL(k_marshal_pairs, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, E, V,
                            power_raw, probs, floor_eff, action_env, p_off01, action_store);
         return hipGetLastError();
     }

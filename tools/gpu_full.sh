@@ -28,6 +28,15 @@ b c5 --veh 16 --ris 256 --mode bcd --steps 300 --warmup 30
 b cached --mode cached
 b noma --noma
 b cached_noma --mode cached --noma
+b replay --replay
+b cached_replay --mode cached --replay
+b sarl --mode sarl
+echo "== streaming yardstick" | tee -a $OUT/round_$TAG.log
+timeout -k 10 300 python tools/membench.py > $OUT/membench_$TAG.jsonl 2>/dev/null; cat $OUT/membench_$TAG.jsonl
+echo "== 2-rank rehearsal on one GPU (gloo for the collective; RCCL needs one GPU per rank)" | tee -a $OUT/round_$TAG.log
+RISVEC_DIST_BACKEND=gloo RISVEC_DEVICE_INDEX=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+  --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 300 --warmup 30 --envs-per-gpu 8192 --no-cpu-baseline \
+  > $OUT/bench_${TAG}_2rank.json 2> $OUT/bench_${TAG}_2rank.err; echo "2rank rc=$?"; tail -1 $OUT/bench_${TAG}_2rank.json | cut -c1-400
 find $OUT -name "*.db" -delete
 find $OUT -name "*kernel_trace.csv" -size +5M -delete
 exit 0

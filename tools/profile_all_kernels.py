@@ -51,7 +51,7 @@ for _ in range(reps):
     if grouper is not None:
         grouper.begin_episode(0)
         mask = grouper.refresh_mask()                                   # k_noma_mask
-        grouper.group(p01, 0)                                          # k_noma_pre + k_noma_solve (all envs solve)
+        grouper.group(p01, 0)                                          # k_noma_group (all envs solve)
         grouper.group(p01, 2)                                          # frozen step
         grouper.flush()                                                # k_noma_flush
     obs = env.tensors["obs"]
@@ -68,6 +68,7 @@ B = dict(
     k_replay_store=E * (2 * 4 * (2 * 5 * V + V * (V + 2) + V + 1) + 5 * V * V + 1),
     k_replay_sample=4096 * (2 * 4 * (2 * 5 * V + V * (V + 2) + V + 1 + V * V) + 2 + 8),
     k_marshal_actions=E * (V * (8 + 4 * V) + 12 * V + 4 * V * (V + 2)),
-    k_noma_mask=E * (4 * V + V * V + 8), k_noma_pre=E * 40, k_noma_solve=E * (8 * V + 4 * V * V * 2 + V * V + 16 * V),
+    k_marshal_pairs=E * (V * (8 + 4 * V) + 12 * V + 4 * V * (V + 2)),
+    k_noma_mask=E * (4 * V + V * V + 8), k_noma_group=E * (8 * V + 4 * V * V * 2 + V * V + 16 * V + 40),
     k_noma_flush=E * (8 * V * V + 8 * V + 4))
 print(json.dumps(dict(E=E, V=V, M=M, reps=reps, algorithmic_bytes=B)))
