@@ -354,3 +354,30 @@ class NomaGrouper:
     @property
     def flags(self) -> torch.Tensor:
         return self._t["flags"]
+
+    # ------------------------------------------------------------------ reference-shaped view, checkpoint
+    def groups_list(self, e: int = 0):
+        """`noma_groups` of env `e` as the reference builds it (TRAIN:1552-1553): pairs `[i, j]` (i < j)
+        in increasing order, then the singles `[k]`.  Host copy; for the E=1 facade / debugging."""
+        p = self._t["partner"][e].cpu().tolist()
+        pairs = sorted([i, q] for i, q in enumerate(p) if 0 <= q < (1 << 16))
+        return pairs + [[k] for k, q in enumerate(p) if q == -1]
+
+    _STATE_KEYS = ("hist", "streak", "partner", "n_groups", "last_global", "best_global", "flags", "mask", "tau")
+
+    def state_dict(self) -> dict:
+        """Episode-scoped pairing state (deferred bookkeeping applied first), host tensors."""
+        self.flush()
+        sd = {k: self._t[k].detach().cpu().clone() for k in self._STATE_KEYS}
+        sd["scalars"] = dict(i_episode=self.i_episode, mask_fresh=self._mask_fresh, have_mask=self._have_mask,
+                             have_reward=self._have_reward, q_now=self._q_now, K_now=self._K_now, calls=self._calls)
+        return sd
+
+    def load_state_dict(self, sd: dict) -> None:
+        self._ensure_device()
+        for k in self._STATE_KEYS:
+            self._t[k].copy_(sd[k].to(self.device))
+        self._t["pending"].zero_()
+        s = sd["scalars"]
+        self.i_episode, self._mask_fresh, self._have_mask = int(s["i_episode"]), bool(s["mask_fresh"]), bool(s["have_mask"])
+        self._have_reward, self._q_now, self._K_now, self._calls = bool(s["have_reward"]), s["q_now"], s["K_now"], int(s["calls"])

@@ -154,6 +154,26 @@ class VecReplayBuffer:
                          torch.as_tensor(np.asarray(state_, dtype=np.float32))[None] if not isinstance(state_, torch.Tensor) else state_[None],
                          bool(done), mk.reshape(1, L, L))
 
+    # ------------------------------------------------------------------ checkpoint
+    _ARRAYS = ("state_memory", "action_memory", "reward_global_memory", "reward_local_memory", "new_state_memory",
+               "terminal_memory", "mask_memory")
+
+    def state_dict(self) -> dict:
+        """The filled part of the ring + its counters (host tensors)."""
+        n = min(self.mem_cntr, self.mem_size)
+        sd = {k: getattr(self, k)[:n].detach().cpu().clone() for k in self._ARRAYS}
+        sd["scalars"] = dict(mem_cntr=self.mem_cntr, mem_size=self.mem_size, samples=self._samples, seed=self.seed)
+        return sd
+
+    def load_state_dict(self, sd: dict) -> None:
+        s = sd["scalars"]
+        if int(s["mem_size"]) != self.mem_size:
+            raise ValueError("replay checkpoint has mem_size %d, this buffer %d" % (s["mem_size"], self.mem_size))
+        n = min(int(s["mem_cntr"]), self.mem_size)
+        for k in self._ARRAYS:
+            getattr(self, k)[:n].copy_(sd[k].to(self.device))
+        self.mem_cntr, self._samples, self.seed = int(s["mem_cntr"]), int(s["samples"]), int(s["seed"])
+
     # ------------------------------------------------------------------ sampling
     def sample_buffer(self, batch_size: int, idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
         """BUF:27-37 -> (states, actions, rewards_g, rewards_l, states_, dones, masks), device tensors.

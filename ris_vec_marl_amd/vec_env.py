@@ -442,7 +442,7 @@ class VecEnviron(ParamAttrs):
 
     # ------------------------------------------------------------------ checkpoint
     _STATE_KEYS = ("pos", "dir", "vel", "dist_r", "ang_r", "pl", "h_r", "theta", "gain", "data_buf", "mec_q",
-                   "rate", "data_t", "data_p")
+                   "rate", "data_t", "data_p", "reward", "over_power", "over_data", "obs", "metrics")
 
     def state_dict(self) -> Dict[str, object]:
         t = self.tensors

@@ -348,3 +348,89 @@ def test_fuzz_configs_vs_oracle(seed):
         prev = T(reward)
     assert np.array_equal(grouper.pair_affinity_hist.cpu().numpy(), np.stack([x.hist for x in eps]))
     assert np.array_equal(grouper.unpaired_streak.cpu().numpy(), np.stack([x.streak for x in eps]))
+
+
+def test_rollout_long_run_checkpoint_and_groups_list():
+    """10 episodes x 50 steps of the whole device-resident rollout (marshal -> group -> fused step ->
+    replay store) at E = 4 096: everything stays finite, every step's grouping is a valid matching,
+    `groups_list` has the reference's list shape, and a checkpoint taken mid-episode (env + grouper +
+    replay) resumes bit-identically."""
+    from ris_vec_marl_amd import NomaGrouper, VecEnviron, VecReplayBuffer, marshal_actions, reference_lanes, apply_yaml_config
+    E, V, M = 4096, 8, 36
+    L = reference_lanes()
+
+    def build():
+        env = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3,
+                         n_envs=E, device=DEV, seed=21)
+        apply_yaml_config(env, None)
+        g = NomaGrouper(env)
+        g.config.min_pair_target = 3
+        g.config.qos_enable = True
+        g.config.qos_R_min_bpsHz = 0.15
+        return env, g, VecReplayBuffer(20 * E, 5, V + 2, V, device=DEV, seed=4)
+
+    def run(env, g, buf, ep0, ep1, rng_seed, snap_at=None):
+        snap = None
+        gen = torch.Generator(device=DEV)
+        for ep in range(ep0, ep1):
+            gen.manual_seed(rng_seed + ep)
+            if env.begin_episode(ep, env_refresh_every=5) or ep == 0:
+                pass
+            g.begin_episode(ep)
+            state_old = env.tensors["obs"].clone()
+            for st in range(50):
+                if snap_at == (ep, st):
+                    snap = (env.state_dict(), g.state_dict(), buf.state_dict(), state_old.clone())
+                refreshed = env.begin_step(st, ris_every=25)
+                mask = g.refresh_mask() if refreshed else None
+                power = torch.rand(E, V, 2, device=DEV, generator=gen) * 2.2 - 1.1
+                probs = torch.softmax(torch.randn(E, V, V, device=DEV, generator=gen), -1)
+                a_env, p01, a_store = marshal_actions(power, probs, env.cpu_share_floor)
+                partner, ng = g.group(p01, st)
+                env.step(a_env, partner, ng, None, fused=True)
+                buf.store_batch(state_old, a_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"],
+                                st == 49, mask)
+                state_old.copy_(env.tensors["obs"])
+        return snap
+
+    env, g, buf = build()
+    env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase()
+    snap = run(env, g, buf, 0, 10, 500, snap_at=(6, 17))
+    for k in ("obs", "reward", "data_buf", "gain", "metrics"):
+        assert torch.isfinite(env.tensors[k]).all(), k
+    p = g._t["partner"].cpu().numpy()
+    paired = p >= 0
+    back = np.take_along_axis(p, np.where(paired, p & 0xFFFF, 0), axis=1)
+    assert np.all(np.where(paired, (back & 0xFFFF) == np.arange(V)[None, :], True))
+    gl = g.groups_list(5)
+    assert sorted(u for grp in gl for u in grp) == list(range(V)) and all(len(x) in (1, 2) for x in gl)
+    assert gl == sorted([x for x in gl if len(x) == 2]) + [x for x in gl if len(x) == 1]
+    assert buf.mem_cntr == 10 * 50 * E and torch.isfinite(buf.state_memory).all()
+    final = (env.tensors["data_buf"].clone(), g.pair_affinity_hist.clone(), g._t["partner"].clone(),
+             buf.reward_global_memory.clone(), buf.mem_cntr)
+
+    # resume from the mid-episode checkpoint in fresh objects: same trajectory
+    env2, g2, buf2 = build()
+    env2.make_new_game()
+    env2.load_state_dict(snap[0]); g2.load_state_dict(snap[1]); buf2.load_state_dict(snap[2])
+    gen = torch.Generator(device=DEV)
+    # replay the tail of episode 6 by hand, then episodes 7..9 through run()
+    gen.manual_seed(500 + 6)
+    for st in range(17):                                    # advance the generator to where the snapshot was taken
+        torch.rand(E, V, 2, device=DEV, generator=gen); torch.randn(E, V, V, device=DEV, generator=gen)
+    state_old = snap[3].clone()
+    for st in range(17, 50):
+        refreshed = env2.begin_step(st, ris_every=25)
+        mask = g2.refresh_mask() if refreshed else None
+        power = torch.rand(E, V, 2, device=DEV, generator=gen) * 2.2 - 1.1
+        probs = torch.softmax(torch.randn(E, V, V, device=DEV, generator=gen), -1)
+        a_env, p01, a_store = marshal_actions(power, probs, env2.cpu_share_floor)
+        partner, ng = g2.group(p01, st)
+        env2.step(a_env, partner, ng, None, fused=True)
+        buf2.store_batch(state_old, a_store, env2.tensors["metrics"], env2.tensors["reward"], env2.tensors["obs"],
+                         st == 49, mask)
+        state_old.copy_(env2.tensors["obs"])
+    run(env2, g2, buf2, 7, 10, 500)
+    assert torch.equal(env2.tensors["data_buf"], final[0])
+    assert torch.equal(g2.pair_affinity_hist, final[1]) and torch.equal(g2._t["partner"], final[2])
+    assert buf2.mem_cntr == final[4] and torch.equal(buf2.reward_global_memory, final[3])
