@@ -15,7 +15,7 @@ reference's own ReplayBuffer, recording the indices `np.random.choice` returned)
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 

@@ -16,7 +16,7 @@ Differences a maintainer must know (also in INTEGRATION.md):
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
 import torch

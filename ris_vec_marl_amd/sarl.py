@@ -10,7 +10,6 @@ goes through `VecEnviron.sarl_step`.
 from __future__ import annotations
 
 import math
-from typing import Optional
 
 import numpy as np
 import torch

@@ -527,7 +527,7 @@ def test_random_phase_and_set_phase():
 def test_trajectory_through_facade():
     """The driver's call protocol (marl_train_bcd.py:545, 1268-1271, 1307-1313, 1601-1611)
     replayed through the E=1 `Environ` facade with the reference's recorded draws."""
-    from ris_vec_marl_amd import Environ, reference_lanes, apply_yaml_config, load_yaml
+    from ris_vec_marl_amd import Environ, reference_lanes
     g = load("trajectory_8_36.npz")
     V, M, n_ep, n_step, refresh_every, bcd_every = (int(x) for x in g["shape"])
     L = reference_lanes()
