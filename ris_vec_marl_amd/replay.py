@@ -145,14 +145,13 @@ class VecReplayBuffer:
 
     def store_transition(self, state, action, reward_g, reward_l, state_, done, mask_flat) -> None:
         """BUF:16-25 with the reference's signature (one transition; NumPy arrays or tensors)."""
+        def row(x):
+            t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x, dtype=np.float32))
+            return t.reshape(1, -1)
         L = self.n_agents
-        mk = torch.as_tensor(np.asarray(mask_flat) != 0 if not isinstance(mask_flat, torch.Tensor) else mask_flat != 0)
-        self.store_batch(torch.as_tensor(np.asarray(state, dtype=np.float32))[None] if not isinstance(state, torch.Tensor) else state[None],
-                         torch.as_tensor(np.asarray(action, dtype=np.float32))[None] if not isinstance(action, torch.Tensor) else action[None],
-                         torch.tensor([float(reward_g)], dtype=torch.float32),
-                         torch.as_tensor(np.asarray(reward_l, dtype=np.float32))[None] if not isinstance(reward_l, torch.Tensor) else reward_l[None],
-                         torch.as_tensor(np.asarray(state_, dtype=np.float32))[None] if not isinstance(state_, torch.Tensor) else state_[None],
-                         bool(done), mk.reshape(1, L, L))
+        mask = mask_flat if isinstance(mask_flat, torch.Tensor) else torch.as_tensor(np.asarray(mask_flat))
+        self.store_batch(row(state), row(action), torch.tensor([float(reward_g)], dtype=torch.float32), row(reward_l),
+                         row(state_), bool(done), (mask != 0).reshape(1, L, L))
 
     # ------------------------------------------------------------------ checkpoint
     _ARRAYS = ("state_memory", "action_memory", "reward_global_memory", "reward_local_memory", "new_state_memory",
