@@ -20,42 +20,43 @@ from typing import Tuple
 import numpy as np
 
 
+def ring_layout(input_shape: int, n_actions: int, n_agents: int):
+    """(array name, row shape, dtype) of the seven ring arrays, in the order `sample_buffer` returns
+    them (BUF:7-14, 29-37)."""
+    S, A, L = input_shape * n_agents, n_actions * n_agents, n_agents
+    return (("state_memory", (S,), np.float32), ("action_memory", (A,), np.float32),
+            ("reward_global_memory", (), np.float32), ("reward_local_memory", (L,), np.float32),
+            ("new_state_memory", (S,), np.float32), ("terminal_memory", (), bool),
+            ("mask_memory", (L * L,), np.float32))
+
+
 class ReplayOracle:
-    """BUF:3-37 with batched stores."""
+    """BUF:3-37 with batched stores: row `mem_cntr % mem_size` of every array takes the next
+    transition (BUF:17-25); sampling indexes all arrays with the same drawn rows (BUF:27-37)."""
 
     def __init__(self, max_size: int, input_shape: int, n_actions: int, n_agents: int):
-        self.mem_size = int(max_size)                                                         # BUF:5
-        self.mem_cntr = 0                                                                     # BUF:6
-        self.state_memory = np.zeros((self.mem_size, input_shape * n_agents), np.float32)     # BUF:7
-        self.action_memory = np.zeros((self.mem_size, n_actions * n_agents), np.float32)      # BUF:8
-        self.reward_global_memory = np.zeros(self.mem_size, np.float32)                       # BUF:9
-        self.reward_local_memory = np.zeros((self.mem_size, n_agents), np.float32)            # BUF:10
-        self.new_state_memory = np.zeros((self.mem_size, input_shape * n_agents), np.float32)  # BUF:11
-        self.terminal_memory = np.zeros(self.mem_size, dtype=bool)                            # BUF:12
-        self.mask_memory = np.zeros((self.mem_size, n_agents * n_agents), np.float32)         # BUF:14
+        self.mem_size, self.mem_cntr = int(max_size), 0
+        self.layout = ring_layout(input_shape, n_actions, n_agents)
+        for name, tail, dtype in self.layout:
+            setattr(self, name, np.zeros((self.mem_size,) + tail, dtype=dtype))
 
     def store_batch(self, state, action, reward_g, reward_l, state_, done, mask_flat) -> None:
-        """E x BUF:16-25, env 0 first.  `done` scalar or [E]; mask_flat None = all ones (TRAIN:1786-1787)."""
+        """E consecutive stores, env 0 first.  `done` scalar or [E]; mask_flat None = all ones
+        (TRAIN:1786-1787)."""
         E = len(state)
-        done = np.broadcast_to(np.asarray(done, dtype=bool), (E,))
         if mask_flat is None:
             mask_flat = np.ones((E, self.mask_memory.shape[1]), np.float32)
+        columns = (state, action, reward_g, reward_l, state_, np.broadcast_to(np.asarray(done, dtype=bool), (E,)),
+                   mask_flat)
         for e in range(E):
-            i = self.mem_cntr % self.mem_size
-            self.state_memory[i] = state[e]
-            self.action_memory[i] = action[e]
-            self.reward_global_memory[i] = reward_g[e]
-            self.reward_local_memory[i] = reward_l[e]
-            self.new_state_memory[i] = state_[e]
-            self.terminal_memory[i] = done[e]
-            self.mask_memory[i] = mask_flat[e]
+            row = self.mem_cntr % self.mem_size
+            for (name, _, _), values in zip(self.layout, columns):
+                getattr(self, name)[row] = values[e]
             self.mem_cntr += 1
 
     def sample(self, batch: np.ndarray) -> Tuple[np.ndarray, ...]:
-        """BUF:27-37 with the drawn indices given (the reference draws np.random.choice(max_mem, n))."""
-        return (self.state_memory[batch], self.action_memory[batch], self.reward_global_memory[batch],
-                self.reward_local_memory[batch], self.new_state_memory[batch], self.terminal_memory[batch],
-                self.mask_memory[batch])
+        """The rows `batch` of every array (the reference draws them with np.random.choice(max_mem, n))."""
+        return tuple(getattr(self, name)[batch] for name, _, _ in self.layout)
 
     def max_mem(self) -> int:
         return min(self.mem_cntr, self.mem_size)                                              # BUF:28
