@@ -196,19 +196,24 @@ k_mobility(Dims d, RisVecParams P, double* __restrict__ pos, int32_t* __restrict
 // instead of one sincospi per element.  A chunk is 128 contiguous bytes of the row.
 constexpr int kGeoChunk = 16;
 
+template <bool STAGED>
 __global__ void __launch_bounds__(kBlock)
 k_geometry(Dims d, const double* __restrict__ pos, float* __restrict__ dist_r,
            float* __restrict__ ang_r, float* __restrict__ pl, float* __restrict__ h_r) {
     const int nchunk = (d.M + kGeoChunk - 1) / kGeoChunk;
-    const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= (long long)d.E * d.V * nchunk) return;
+    long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const bool in_range = idx < (long long)d.E * d.V * nchunk;
+    if (!in_range) {
+        if constexpr (!STAGED) return;
+        idx = (long long)d.E * d.V * nchunk - 1;   // staged form: stay for the barrier, recompute the last chunk
+    }
     const long long ev = idx / nchunk;
     const int m0 = (int)(idx % nchunk) * kGeoChunk;
     const double x = pos[ev * 2], y = pos[ev * 2 + 1];
     const double dx = x - kRisX, dy = y - kRisY, dz = kVehZ - kRisZ;
     const double dist = sqrt(dx * dx + dy * dy + dz * dz);                  // ENV:245-246
     const double ang = dx / dist;                                           // ENV:248
-    if (m0 == 0) {
+    if (m0 == 0 && in_range) {
         dist_r[ev] = (float)dist;
         ang_r[ev] = (float)ang;
         const double d_br = sqrt((kBsX - kRisX) * (kBsX - kRisX) + (kBsY - kRisY) * (kBsY - kRisY)
@@ -221,6 +226,31 @@ k_geometry(Dims d, const double* __restrict__ pos, float* __restrict__ dist_r,
     double zr = zc, zi = -zs;
     const double wr = wc, wi = -ws;
     float* out = h_r + (ev * d.M + m0) * 2;
+    if constexpr (STAGED) {
+        // M % 16 == 0: every lane owns one full 128-byte chunk and the block's 256 chunks are contiguous
+        // in h_r.  Park the chunks in LDS (rows padded to 144 B against bank conflicts) and write the
+        // block's 32 KB back with consecutive lanes on consecutive 16-byte pieces (1 KB per instruction)
+        // instead of 64 partial lines per instruction.
+        __shared__ float4 s_stage[kBlock * 9];
+        float4* row = s_stage + threadIdx.x * 9;
+#pragma unroll
+        for (int k = 0; k < kGeoChunk; k += 2) {
+            const double ar = zr, ai = zi;
+            const double br = ar * wr - ai * wi, bi = ar * wi + ai * wr;        // next element
+            zr = br * wr - bi * wi; zi = br * wi + bi * wr;                     // the one after
+            row[k / 2] = make_float4((float)ar, (float)ai, (float)br, (float)bi);
+        }
+        __syncthreads();
+        const long long block_first = (long long)blockIdx.x * kBlock;          // first chunk of this block
+        const long long n_chunks = (long long)d.E * d.V * nchunk;
+        float4* gout = reinterpret_cast<float4*>(h_r) + block_first * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int f = k * kBlock + threadIdx.x;                             // 16-byte piece within the block
+            if (block_first + f / 8 < n_chunks) gout[f] = s_stage[(f / 8) * 9 + (f % 8)];
+        }
+        return;
+    }
     const bool vec = (d.M & 1) == 0;               // even M: rows are 16-byte aligned, pairs never straddle
 #pragma unroll
     for (int k = 0; k < kGeoChunk; k += 2) {
@@ -343,8 +373,12 @@ hipError_t launch_mobility(const RisVecState& s, const RisVecParams& p, const fl
 
 hipError_t launch_geometry(const RisVecState& s, const RisVecParams&, hipStream_t st) {
     const long long n = (long long)s.n_envs * s.n_veh * ((s.n_ris + kGeoChunk - 1) / kGeoChunk);
-    hipLaunchKernelGGL(k_geometry, dim3(blocks_for(n)), dim3(kBlock), 0, st, dims_of(s), s.pos,
-                       s.dist_r, s.ang_r, s.pl, s.h_r);
+    if (s.n_ris % kGeoChunk == 0)
+        hipLaunchKernelGGL(k_geometry<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, dims_of(s), s.pos,
+                           s.dist_r, s.ang_r, s.pl, s.h_r);
+    else
+        hipLaunchKernelGGL(k_geometry<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, dims_of(s), s.pos,
+                           s.dist_r, s.ang_r, s.pl, s.h_r);
     return hipGetLastError();
 }
 
