@@ -61,6 +61,11 @@ hipError_t launch_replay_sample(const RisVecReplay& rb, long long max_mem, int b
 hipError_t launch_marshal_actions(int E, int V, const float* power_raw, const float* probs, float floor_eff,
                                   float* action_env, float* p_off01, float* action_store, hipStream_t st);
 
+hipError_t launch_policy_sample(int E, int V, long long env_offset, const float* heads, const uint8_t* mask,
+                                const float* tau, const float* eps, const float* expo, uint64_t seed, uint32_t counter,
+                                float floor_eff, float* power_raw, float* probs, float* onehot, float* action_env,
+                                float* p_off01, float* action_store, hipStream_t st);
+
 inline Dims dims_of(const RisVecState& s) {
     return Dims{s.n_envs, s.n_veh, s.n_ris, s.control_bit, (long long)s.env_offset};
 }

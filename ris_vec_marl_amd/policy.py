@@ -1,0 +1,132 @@
+"""f3: batched `choose_action` -- the reference's per-agent SAC policies
+(`Simulation-MARL-BCD/sac_agent.py`, SAC below: `PolicyNetwork` SAC:9-131, `Agent.choose_action`
+SAC:187-225) evaluated for all E envs and all V agents at once, on the GPU.
+
+The driver calls `agents[i].choose_action(obs_i, mask=mask_row)` V times per step, each a batch-1
+forward with a host round trip (TRAIN:1373-1384).  Here the V networks' weights are stacked and the
+three small GEMMs of `forward` (5 -> fc1 -> fc2 -> {mu, log_std, intent_logits}) run as `torch.bmm`
+(rocBLAS: plain library GEMMs); everything after them -- clamp, Normal sample + tanh, logits mask,
+Gumbel-softmax, arg-max one-hot AND the marshalling of TRAIN:1386-1396, 1601-1608, 1776-1784 -- is one
+hand-written HIP launch (`risvec_policy_sample`, csrc/k_policy.hip).  No CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Mapping, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+
+_LAYERS = ("fc1", "fc2", "mu", "log_std", "intent_logits")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class BatchedPolicy:
+    """V stacked `PolicyNetwork`s (SAC:9-60): input_dims -> fc1 -> LayerNorm -> ReLU -> fc2 -> LayerNorm
+    -> ReLU -> heads mu[n_actions], log_std[n_actions], intent_logits[n_agents]."""
+
+    def __init__(self, n_agents: int, input_dims: int = 5, fc1_dims: int = 512, fc2_dims: int = 256,
+                 n_actions: int = 2, device="cuda", seed: int = 0, env_offset: int = 0):
+        N.load()
+        if n_actions != 2:
+            raise ValueError("the reference's power head has 2 outputs (offload, local); got %d" % n_actions)
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("ris_vec_marl_amd needs a HIP device; there is no CPU fallback")
+        self.n_agents, self.input_dims, self.fc1_dims, self.fc2_dims = int(n_agents), int(input_dims), int(fc1_dims), int(fc2_dims)
+        self.seed, self.env_offset, self._calls = int(seed), int(env_offset), 0
+        V, dev = self.n_agents, self.device
+        g = torch.Generator(device="cpu").manual_seed(seed)
+
+        def uni(*shape, r):
+            return ((torch.rand(*shape, generator=g) * 2 - 1) * r).to(dev)
+        f1, f2, f3 = 1.0 / math.sqrt(fc1_dims), 1.0 / math.sqrt(fc2_dims), 0.003        # SAC:36-50
+        H = 4 + V
+        self.W1, self.b1 = uni(V, input_dims, fc1_dims, r=f1), uni(V, 1, fc1_dims, r=f1)
+        self.W2, self.b2 = uni(V, fc1_dims, fc2_dims, r=f2), uni(V, 1, fc2_dims, r=f2)
+        self.Wh, self.bh = uni(V, fc2_dims, H, r=f3), uni(V, 1, H, r=f3)               # [mu | log_std | intent_logits]
+        self.ln1_w, self.ln1_b = torch.ones(V, 1, fc1_dims, device=dev), torch.zeros(V, 1, fc1_dims, device=dev)
+        self.ln2_w, self.ln2_b = torch.ones(V, 1, fc2_dims, device=dev), torch.zeros(V, 1, fc2_dims, device=dev)
+        self.tau = torch.full((V,), 2.0, device=dev)                                    # SAC:54 (annealed by the driver)
+
+    # ------------------------------------------------------------------ weights
+    def load_agent_state_dict(self, agent: int, sd: Mapping[str, object]) -> None:
+        """Take agent `agent`'s weights from a reference `PolicyNetwork.state_dict()` (tensors or arrays;
+        Linear weights are [out, in] there).  Load checkpoints with `torch.load(..., weights_only=True)`."""
+        t = lambda k: torch.as_tensor(sd[k], dtype=torch.float32).to(self.device)   # noqa: E731
+        a = int(agent)
+        self.W1[a], self.b1[a, 0] = t("fc1.weight").T, t("fc1.bias")
+        self.W2[a], self.b2[a, 0] = t("fc2.weight").T, t("fc2.bias")
+        self.Wh[a] = torch.cat([t("mu.weight"), t("log_std.weight"), t("intent_logits.weight")], 0).T
+        self.bh[a, 0] = torch.cat([t("mu.bias"), t("log_std.bias"), t("intent_logits.bias")], 0)
+        self.ln1_w[a, 0], self.ln1_b[a, 0] = t("bn1.weight"), t("bn1.bias")
+        self.ln2_w[a, 0], self.ln2_b[a, 0] = t("bn2.weight"), t("bn2.bias")
+        if "tau" in sd:
+            self.tau[a] = float(torch.as_tensor(sd["tau"]))
+
+    def set_tau(self, tau: float) -> None:
+        """The driver's temperature annealing (TRAIN:1804-1815 sets every agent's `policy.tau`; the optional hard straight-through mode of TRAIN:1816-1818, off by default, is not built)."""
+        self.tau.fill_(float(tau))
+
+    # ------------------------------------------------------------------ forward
+    def forward_heads(self, obs: torch.Tensor) -> torch.Tensor:
+        """SAC:62-78 for every agent: obs [E,V,input_dims] -> [V,E,4+V] rows (mu, log_std (unclamped),
+        intent_logits).  Three batched GEMMs + two LayerNorms; library kernels."""
+        x = obs.to(self.device, torch.float32).transpose(0, 1)                          # [V,E,in]
+        F = torch.nn.functional
+        h = torch.baddbmm(self.b1, x, self.W1)
+        h = torch.relu(F.layer_norm(h, (self.fc1_dims,)) * self.ln1_w + self.ln1_b)
+        h = torch.baddbmm(self.b2, h, self.W2)
+        h = torch.relu(F.layer_norm(h, (self.fc2_dims,)) * self.ln2_w + self.ln2_b)
+        return torch.baddbmm(self.bh, h, self.Wh).contiguous()
+
+    def choose_action(self, obs: torch.Tensor, mask: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None,
+                      expo: Optional[torch.Tensor] = None, cpu_share_floor: Optional[float] = None,
+                      want_onehot: bool = True) -> Tuple[torch.Tensor, ...]:
+        """`agents[i].choose_action(obs_i, mask=mask[i])` for every env and agent (SAC:187-225).
+        obs [E,V,5]; mask [E,V,V] uint8/bool (the NOMA mask: row v = who agent v may pick) or None.
+        Returns (power_action [E,V,2], intent_probs [E,V,V], intent_onehot [E,V,V] or None); with
+        `cpu_share_floor` given, additionally the marshalled (action_env [E,2,V], p_off01 [E,V],
+        action_store [E,V*(V+2)]) exactly as `marshal_actions` would produce them -- same launch.
+        `eps` [E,V,2] / `expo` [E,V,V] inject the N(0,1) / Exp(1) draws (parity); default Philox."""
+        E, V = int(obs.shape[0]), self.n_agents
+        if tuple(obs.shape) != (E, V, self.input_dims):
+            raise ValueError("obs must have shape [E, %d, %d]" % (V, self.input_dims))
+        heads = self.forward_heads(obs)
+        dev = self.device
+        mk = None
+        if mask is not None:
+            mk = mask.to(dev)
+            mk = (mk != 0).to(torch.uint8) if mk.dtype != torch.uint8 else mk
+            mk = mk.reshape(E, V, V).contiguous()
+        ep = None if eps is None else eps.to(dev, torch.float32).reshape(E, V, 2).contiguous()
+        ex = None if expo is None else expo.to(dev, torch.float32).reshape(E, V, V).contiguous()
+        power = torch.empty(E, V, 2, device=dev)
+        probs = torch.empty(E, V, V, device=dev)
+        onehot = torch.empty(E, V, V, device=dev) if want_onehot else None
+        marsh = cpu_share_floor is not None
+        a_env = torch.empty(E, 2, V, device=dev) if marsh else None
+        p01 = torch.empty(E, V, device=dev) if marsh else None
+        a_store = torch.empty(E, V * (V + 2), device=dev) if marsh else None
+        self._calls += 1
+        N.check(N.load().risvec_policy_sample(
+            E, V, self.env_offset, heads.data_ptr(), _ptr(mk), self.tau.data_ptr(), _ptr(ep), _ptr(ex), self.seed,
+            self._calls, float(cpu_share_floor) if marsh else 0.0, power.data_ptr(), probs.data_ptr(), _ptr(onehot),
+            _ptr(a_env), _ptr(p01), _ptr(a_store), torch.cuda.current_stream(dev).cuda_stream))
+        out = (power, probs, onehot)
+        return out + (a_env, p01, a_store) if marsh else out
+
+    # ------------------------------------------------------------------ checkpoint
+    _KEYS = ("W1", "b1", "W2", "b2", "Wh", "bh", "ln1_w", "ln1_b", "ln2_w", "ln2_b", "tau")
+
+    def state_dict(self) -> dict:
+        return {k: getattr(self, k).detach().cpu().clone() for k in self._KEYS}
+
+    def load_state_dict(self, sd: Mapping[str, torch.Tensor]) -> None:
+        for k in self._KEYS:
+            getattr(self, k).copy_(sd[k].to(self.device))

@@ -1,0 +1,122 @@
+"""GPU parity tests of the batched choose_action: `BatchedPolicy` (torch.bmm for the
+three GEMMs + the hand-written sampling / marshalling epilogue risvec_policy_sample) against the vectors
+captured from the reference's own PolicyNetwork objects and against oracle/policy_oracle.py.
+
+Tolerance: the reference computes in float32 on the CPU; here float32 on the GPU with another
+accumulation order -> 2e-5 absolute on tanh / softmax outputs (values in [-1,1] / [0,1]); one-hot exact
+wherever the top two probabilities differ by more than 1e-4; the marshalled outputs must equal what
+`marshal_actions` makes of the same power / probs bit for bit."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import policy_oracle as PO  # noqa: E402  (checker)
+from oracle import risvec_oracle as orc  # noqa: E402  (checker)
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def agent_weights(d, a):
+    pre = "a%d." % a
+    return {k[len(pre):]: d[k] for k in d.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "policy_*.npz"))), ids=os.path.basename)
+def test_vs_golden(path):
+    from ris_vec_marl_amd import BatchedPolicy, marshal_actions
+    d = np.load(path)
+    V, B = int(d["V"]), int(d["B"])
+    pol = BatchedPolicy(V, 5, int(d["fc1"]), int(d["fc2"]), device=DEV)
+    for a in range(V):
+        pol.load_agent_state_dict(a, agent_weights(d, a))
+        pol.tau[a] = float(d["tau"][a])
+    obs = np.stack([d["state"][a] for a in range(V)], 1)                      # [B,V,5]
+    mask = np.stack([d["mask"][a] if d["has_mask"][a] else np.ones((B, V), np.float32) for a in range(V)], 1)
+    eps = np.stack([d["eps"][a] for a in range(V)], 1)
+    expo = np.stack([d["expo"][a] for a in range(V)], 1)
+    heads = pol.forward_heads(T(obs)).cpu().numpy()                            # [V,B,4+V]
+    for a in range(V):
+        np.testing.assert_allclose(heads[a][:, 0:2], d["mu"][a], atol=5e-6)
+        np.testing.assert_allclose(np.clip(heads[a][:, 2:4], -20, 2), d["log_std"][a], atol=5e-6)
+        np.testing.assert_allclose(heads[a][:, 4:], d["logits"][a], atol=5e-6)
+    power, probs, onehot, a_env, p01, a_store = pol.choose_action(T(obs), T(mask), T(eps), T(expo), cpu_share_floor=0.1)
+    for a in range(V):
+        np.testing.assert_allclose(power.cpu().numpy()[:, a], d["power"][a], atol=2e-5)
+        np.testing.assert_allclose(probs.cpu().numpy()[:, a], d["probs"][a], atol=2e-5)
+        clear = PO.top2_gap(d["probs"][a]) > 1e-4
+        assert np.array_equal(onehot.cpu().numpy()[:, a][clear], d["onehot"][a][clear])
+    m_env, m_p01, m_store = marshal_actions(power, probs, 0.1)               # fused marshalling == separate launch
+    assert torch.equal(a_env, m_env) and torch.equal(p01, m_p01) and torch.equal(a_store, m_store)
+
+
+def test_reference_sized_networks_vs_oracle():
+    """The driver's sizes (512 / 256 hidden, config A_fc1_dims / A_fc2_dims), 8 agents, E = 1 024, random
+    weights in the reference's init ranges: device float32 vs the float64 oracle."""
+    from ris_vec_marl_amd import BatchedPolicy
+    V, E = 8, 1024
+    rng = np.random.default_rng(3)
+    pol = BatchedPolicy(V, 5, 512, 256, device=DEV, seed=11)
+    with torch.no_grad():                       # heads start at +-0.003: widen them so the outputs are not all ~0
+        pol.Wh.mul_(60.0)
+    obs = rng.uniform(0, 1.2, (E, V, 5)).astype(np.float32)
+    mask = (rng.uniform(size=(E, V, V)) < 0.7).astype(np.uint8)
+    eps = rng.normal(size=(E, V, 2)).astype(np.float32)
+    expo = rng.exponential(size=(E, V, V)).astype(np.float32)
+    pol.set_tau(1.0)
+    power, probs, onehot = pol.choose_action(T(obs), T(mask), T(eps), T(expo))
+    sd = {k: v.numpy() for k, v in pol.state_dict().items()}
+    for a in range(V):
+        w = {"fc1.weight": sd["W1"][a].T, "fc1.bias": sd["b1"][a, 0], "fc2.weight": sd["W2"][a].T, "fc2.bias": sd["b2"][a, 0],
+             "bn1.weight": sd["ln1_w"][a, 0], "bn1.bias": sd["ln1_b"][a, 0], "bn2.weight": sd["ln2_w"][a, 0],
+             "bn2.bias": sd["ln2_b"][a, 0], "mu.weight": sd["Wh"][a][:, 0:2].T, "mu.bias": sd["bh"][a, 0, 0:2],
+             "log_std.weight": sd["Wh"][a][:, 2:4].T, "log_std.bias": sd["bh"][a, 0, 2:4],
+             "intent_logits.weight": sd["Wh"][a][:, 4:].T, "intent_logits.bias": sd["bh"][a, 0, 4:]}
+        po, yo, oh = PO.choose_action(w, obs[:, a], mask[:, a].astype(np.float64), 1.0, eps[:, a], expo[:, a])
+        np.testing.assert_allclose(power.cpu().numpy()[:, a], po, atol=3e-5)
+        np.testing.assert_allclose(probs.cpu().numpy()[:, a], yo, atol=3e-5)
+        clear = PO.top2_gap(yo) > 1e-3
+        assert clear.mean() > 0.9 and np.array_equal(onehot.cpu().numpy()[:, a][clear], oh[clear])
+
+
+def test_full_size_properties_and_philox():
+    """E = 32 768 x 8 agents, production draws: probabilities sum to 1, blocked partners get none, the
+    one-hot marks the arg-max, tanh range; the Philox draws are the documented ones (site 9 / 10)."""
+    from ris_vec_marl_amd import BatchedPolicy
+    V, E = 8, 32768
+    rng = np.random.default_rng(5)
+    pol = BatchedPolicy(V, 5, 512, 256, device=DEV, seed=77, env_offset=4096)
+    with torch.no_grad():
+        pol.Wh.mul_(100.0)
+    obs = T(rng.uniform(0, 1.2, (E, V, 5)).astype(np.float32))
+    mask = (rng.uniform(size=(E, V, V)) < 0.7).astype(np.uint8)
+    mask[:100] = 0                                              # all-zero rows are opened up
+    power, probs, onehot = pol.choose_action(obs, T(mask))
+    p, y, oh = power.cpu().numpy(), probs.cpu().numpy(), onehot.cpu().numpy()
+    assert np.all(np.abs(p) <= 1.0) and np.isfinite(y).all()
+    np.testing.assert_allclose(y.sum(-1), 1.0, atol=1e-5)
+    blocked = (mask == 0) & (mask.sum(-1, keepdims=True) > 0)
+    assert np.all(y[blocked] == 0.0)
+    assert np.all(y[:100].min(-1) > 0)
+    assert np.array_equal(oh.argmax(-1), y.argmax(-1)) and np.all(oh.sum(-1) == 1.0)
+    # the draws: eps = Box-Muller of Philox(seed; env, agent, call, 9); recompute power from heads
+    heads = pol.forward_heads(obs).cpu().numpy().astype(np.float64)      # [V,E,4+V]
+    e_ids = np.arange(4096, 4096 + E, dtype=np.uint64)
+    for a in (0, 5):
+        x = orc.philox4x32(e_ids, np.full(E, a, np.uint64), np.full(E, 1, np.uint64), np.full(E, 9, np.uint64), 77)
+        u1 = ((x[0] >> 8).astype(np.float64) + 1.0) * 2.0 ** -24
+        u2 = (x[1] >> 8).astype(np.float64) * 2.0 ** -24
+        r = np.sqrt(-2.0 * np.log(u1))
+        n0, n1 = r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)
+        ls = np.clip(heads[a][:, 2:4], -20, 2)
+        np.testing.assert_allclose(p[:, a, 0], np.tanh(n0 * np.exp(ls[:, 0]) + heads[a][:, 0]), atol=2e-4)
+        np.testing.assert_allclose(p[:, a, 1], np.tanh(n1 * np.exp(ls[:, 1]) + heads[a][:, 1]), atol=2e-4)
