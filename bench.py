@@ -177,7 +177,13 @@ def main() -> None:
     ap.add_argument("--replay", action="store_true",
                     help="full device-resident rollout step (SURVEY 8 f3): marshal synthetic policy outputs, group "
                          "(implies --noma), step, append the E transitions to the HBM replay ring")
+    ap.add_argument("--policy", action="store_true",
+                    help="with --replay: the actions come from the batched SAC policy (BatchedPolicy: 8 x (5-512-256) "
+                         "networks over all envs, rocBLAS GEMMs + the fused sampling/marshalling kernel) instead of "
+                         "pre-drawn synthetic policy outputs")
     args = ap.parse_args()
+    if args.policy:
+        args.replay = True
     if args.replay:
         args.noma = True
 
@@ -240,6 +246,13 @@ def main() -> None:
         a_store = torch.empty(E, V * (V + 2), device=device)
         floor = float(env.cpu_share_floor)
         marshal = lambda: marshal_actions(power_raw, probs, floor, out=(action, p_off01, a_store))   # noqa: E731
+        if args.policy:
+            from ris_vec_marl_amd import BatchedPolicy
+            policy = BatchedPolicy(V, 5, 512, 256, device=device, seed=rank, env_offset=start)
+
+            def marshal():                 # policy forward + sample + marshal; outputs land in the bound tensors
+                out = policy.choose_action(env.tensors["obs"], grouper.mask, cpu_share_floor=floor, want_onehot=False)
+                action.copy_(out[3]); p_off01.copy_(out[4]); a_store.copy_(out[5])
         marshal()
         replay = VecReplayBuffer(16 * E, 5, V + 2, V, device=device)
         store = replay.bind_store(None, a_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"],
@@ -330,6 +343,7 @@ def main() -> None:
                                      if args.noma else "synthetic fixed groups"),
                    "replay": ("marshal + HBM replay ring store every step (%d B per transition)"
                               % (4 * (10 * V + V * (V + 2) + V + 1 + V * V) + 1) if args.replay else "off"),
+                   "policy": "BatchedPolicy 8x(5-512-256), every step" if args.policy else "synthetic outputs",
                    "agent_steps_per_s": E * world * args.steps / dt * V},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

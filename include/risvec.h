@@ -437,6 +437,19 @@ int risvec_policy_sample(int32_t n_envs, int32_t n_veh, int64_t env_offset, cons
                          float cpu_share_floor, float *power_raw, float *probs, float *onehot, float *action_env,
                          float *p_off01, float *action_store, risvec_stream_t stream);
 
+/* The two non-GEMM ends of PolicyNetwork.forward (sac_agent.py:62-78), all agents and envs per launch;
+ * the fc1 x fc2 product in between is a plain batched GEMM (rocBLAS).  Row-major float32 everywhere.
+ *   layer1: obs [E,V,in] , W1 [V,in,F1] (= fc1.weight^T), b1 / ln_w / ln_b [V,F1]
+ *           -> out [V,E,F1] = relu(LayerNorm(fc1(obs)))                      (F1 <= 1024; in*F1 must fit LDS)
+ *   heads : g [V,E,F2] (= fc2 product; b2 [V,F2] its bias, added here, or NULL), ln_w / ln_b [V,F2], Wh [V,F2,H] (= [mu|log_std|intent_logits]
+ *           weights transposed, H = 4 + V), bh [V,H]
+ *           -> heads [V,E,H], the input of risvec_policy_sample                (F2 <= 1024) */
+int risvec_policy_layer1(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t f1, const float *obs, const float *W1,
+                         const float *b1, const float *ln_w, const float *ln_b, float *out, risvec_stream_t stream);
+int risvec_policy_heads(int32_t n_envs, int32_t n_veh, int32_t f2, int32_t n_heads, const float *g, const float *b2,
+                        const float *ln_w, const float *ln_b, const float *Wh, const float *bh, float *heads,
+                        risvec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,6 +151,8 @@ _PROTOS = {
     "risvec_replay_sample": (C.c_int, [C.POINTER(RisVecReplay), C.c_int64, C.c_int32, _FP, C.c_uint64, C.c_uint32,
                                        _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "risvec_marshal_actions": (C.c_int, [C.c_int32, C.c_int32, _FP, _FP, C.c_float, _FP, _FP, _FP, _FP]),
+    "risvec_policy_layer1": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "risvec_policy_heads": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "risvec_policy_sample": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _FP, _FP, _FP, _FP, _FP, C.c_uint64, C.c_uint32,
                                        C.c_float, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
 }

@@ -481,4 +481,30 @@ int risvec_policy_sample(int32_t n_envs, int32_t n_veh, int64_t env_offset, cons
                                                    (hipStream_t)stream));
 }
 
+int risvec_policy_layer1(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t f1, const float* obs, const float* W1,
+                         const float* b1, const float* ln_w, const float* ln_b, float* out, risvec_stream_t stream) {
+    const char* fn = "risvec_policy_layer1";
+    if (n_envs < 1 || n_veh < 1 || n_veh > 65535) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d n_veh=%d", fn, n_envs, n_veh);
+    if (in_dims < 1 || f1 < 1 || f1 > 1024 || (long long)(in_dims + 3) * f1 * 4 > 64 * 1024)
+        return fail(RISVEC_ERR_SHAPE, "%s: in_dims=%d f1=%d (f1 <= 1024, (in+3)*f1 floats must fit 64 KB of LDS)", fn,
+                    in_dims, f1);
+    REQ_PTR(obs, "obs"); REQ_PTR(W1, "W1"); REQ_PTR(b1, "b1"); REQ_PTR(ln_w, "ln_w"); REQ_PTR(ln_b, "ln_b"); REQ_PTR(out, "out");
+    return finish(fn, risvec::launch_policy_layer1(n_envs, n_veh, in_dims, f1, obs, W1, b1, ln_w, ln_b, out,
+                                                   (hipStream_t)stream));
+}
+
+int risvec_policy_heads(int32_t n_envs, int32_t n_veh, int32_t f2, int32_t n_heads, const float* g, const float* b2,
+                        const float* ln_w, const float* ln_b, const float* Wh, const float* bh, float* heads,
+                        risvec_stream_t stream) {
+    const char* fn = "risvec_policy_heads";
+    if (n_envs < 1 || n_veh < 1 || n_veh > 65535) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d n_veh=%d", fn, n_envs, n_veh);
+    if (f2 < 1 || f2 > 1024 || n_heads < 1 || ((long long)3 * f2 + (long long)f2 * n_heads + n_heads) * 4 > 64 * 1024)
+        return fail(RISVEC_ERR_SHAPE, "%s: f2=%d n_heads=%d (f2 <= 1024, f2*(n_heads+2) floats must fit 64 KB of LDS)", fn,
+                    f2, n_heads);
+    REQ_PTR(g, "g"); OPT_PTR(b2, "b2"); REQ_PTR(ln_w, "ln_w"); REQ_PTR(ln_b, "ln_b"); REQ_PTR(Wh, "Wh"); REQ_PTR(bh, "bh");
+    REQ_PTR(heads, "heads");
+    return finish(fn, risvec::launch_policy_heads(n_envs, n_veh, f2, n_heads, g, b2, ln_w, ln_b, Wh, bh, heads,
+                                                  (hipStream_t)stream));
+}
+
 }  // extern "C"

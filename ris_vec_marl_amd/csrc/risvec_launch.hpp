@@ -66,6 +66,11 @@ hipError_t launch_policy_sample(int E, int V, long long env_offset, const float*
                                 float floor_eff, float* power_raw, float* probs, float* onehot, float* action_env,
                                 float* p_off01, float* action_store, hipStream_t st);
 
+hipError_t launch_policy_layer1(int E, int V, int IN, int F, const float* obs, const float* W1, const float* b1,
+                                const float* lw, const float* lb, float* out, hipStream_t st);
+hipError_t launch_policy_heads(int E, int V, int F, int H, const float* g, const float* b2, const float* lw,
+                               const float* lb, const float* Wh, const float* bh, float* heads, hipStream_t st);
+
 inline Dims dims_of(const RisVecState& s) {
     return Dims{s.n_envs, s.n_veh, s.n_ris, s.control_bit, (long long)s.env_offset};
 }

@@ -76,7 +76,26 @@ class BatchedPolicy:
     # ------------------------------------------------------------------ forward
     def forward_heads(self, obs: torch.Tensor) -> torch.Tensor:
         """SAC:62-78 for every agent: obs [E,V,input_dims] -> [V,E,4+V] rows (mu, log_std (unclamped),
-        intent_logits).  Three batched GEMMs + two LayerNorms; library kernels."""
+        intent_logits).  fc1 + LayerNorm + ReLU is one hand-written launch (its "GEMM" has K = 5), the
+        fc1 x fc2 product is a batched rocBLAS GEMM, and LayerNorm + ReLU + the three heads are a second
+        hand-written launch, so the normalised hidden layers never make an extra HBM round trip."""
+        E, V = int(obs.shape[0]), self.n_agents
+        x = obs.to(self.device, torch.float32).contiguous()
+        lib, stream = N.load(), torch.cuda.current_stream(self.device).cuda_stream
+        h1 = torch.empty(V, E, self.fc1_dims, device=self.device)
+        N.check(lib.risvec_policy_layer1(E, V, self.input_dims, self.fc1_dims, x.data_ptr(), self.W1.data_ptr(),
+                                         self.b1.data_ptr(), self.ln1_w.data_ptr(), self.ln1_b.data_ptr(), h1.data_ptr(),
+                                         stream))
+        g2 = torch.bmm(h1, self.W2)                              # [V,E,fc2]: library GEMM (its bias is added downstream)
+        heads = torch.empty(V, E, 4 + V, device=self.device)
+        N.check(lib.risvec_policy_heads(E, V, self.fc2_dims, 4 + V, g2.data_ptr(), self.b2.data_ptr(), self.ln2_w.data_ptr(),
+                                        self.ln2_b.data_ptr(), self.Wh.data_ptr(), self.bh.data_ptr(), heads.data_ptr(),
+                                        stream))
+        return heads
+
+    def forward_heads_torch(self, obs: torch.Tensor) -> torch.Tensor:
+        """The same forward with library kernels only (torch.bmm / layer_norm): the fp32 reference the
+        hand-written launches are tested against."""
         x = obs.to(self.device, torch.float32).transpose(0, 1)                          # [V,E,in]
         F = torch.nn.functional
         h = torch.baddbmm(self.b1, x, self.W1)

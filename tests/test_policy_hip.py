@@ -120,3 +120,20 @@ def test_full_size_properties_and_philox():
         ls = np.clip(heads[a][:, 2:4], -20, 2)
         np.testing.assert_allclose(p[:, a, 0], np.tanh(n0 * np.exp(ls[:, 0]) + heads[a][:, 0]), atol=2e-4)
         np.testing.assert_allclose(p[:, a, 1], np.tanh(n1 * np.exp(ls[:, 1]) + heads[a][:, 1]), atol=2e-4)
+
+
+@pytest.mark.parametrize("dims", [(8, 512, 256), (4, 40, 24), (16, 128, 64), (3, 1000, 70)])
+def test_handwritten_forward_vs_library_forward(dims):
+    """k_policy_layer1 / k_policy_heads (+ the rocBLAS fc2 GEMM) against the same forward done with library
+    kernels only (torch.bmm + layer_norm), fp32 both: 1e-5 relative to the row scale."""
+    from ris_vec_marl_amd import BatchedPolicy
+    V, F1, F2 = dims
+    E = 777
+    pol = BatchedPolicy(V, 5, F1, F2, device=DEV, seed=V)
+    with torch.no_grad():
+        pol.Wh.mul_(50.0)
+        pol.ln1_w.uniform_(0.5, 1.5); pol.ln1_b.uniform_(-0.2, 0.2); pol.ln2_w.uniform_(0.5, 1.5); pol.ln2_b.uniform_(-0.2, 0.2)
+    obs = torch.rand(E, V, 5, device=DEV) * 1.2
+    a, b = pol.forward_heads(obs), pol.forward_heads_torch(obs)
+    scale = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-3)
+    assert float(((a - b).abs() / scale).max()) < 2e-5
