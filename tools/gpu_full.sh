@@ -31,6 +31,7 @@ b cached_noma --mode cached --noma
 b replay --replay
 b cached_replay --mode cached --replay
 b sarl --mode sarl
+b policy --policy --steps 300 --warmup 30
 echo "== streaming yardstick" | tee -a $OUT/round_$TAG.log
 timeout -k 10 300 python tools/membench.py > $OUT/membench_$TAG.jsonl 2>/dev/null; cat $OUT/membench_$TAG.jsonl
 echo "== 2-rank rehearsal on one GPU (gloo for the collective; RCCL needs one GPU per rank)" | tee -a $OUT/round_$TAG.log
