@@ -427,15 +427,16 @@ int risvec_marshal_actions(int32_t n_envs, int32_t n_veh, const float *power_raw
 /* Batched choose_action, sampling epilogue (sac_agent.py:80-131, 187-225) + marshalling in one
  * launch.  heads [V, E, 4+V] float32 = per agent the rows (mu[2], log_std[2], intent_logits[V]) its
  * PolicyNetwork.forward produced (sac_agent.py:62-78: three small GEMMs, library work); mask [E,V,V] 0/1
- * bytes or NULL; tau [V] the agents' Gumbel temperatures; eps [E,V,2] ~ N(0,1) and expo [E,V,V] ~ Exp(1)
+ * bytes or NULL; tau [V] the agents' Gumbel temperatures; hard [V] bytes or NULL: per agent the straight-through
+ * one-hot form of F.gumbel_softmax (marl_train_bcd.py:1816-1818); eps [E,V,2] ~ N(0,1) and expo [E,V,V] ~ Exp(1)
  * inject the draws of Normal.sample / F.gumbel_softmax (NULL: Philox keyed by env_offset + e).
  * Outputs: power_raw [E,V,2] (tanh-squashed), probs [E,V,V] (soft Gumbel-softmax), onehot [E,V,V] or
  * NULL; and, each optional, exactly what risvec_marshal_actions would produce from them:
  * action_env [E,2,V], p_off01 [E,V], action_store [E,V*(V+2)]. */
 int risvec_policy_sample(int32_t n_envs, int32_t n_veh, int64_t env_offset, const float *heads, const uint8_t *mask,
-                         const float *tau, const float *eps, const float *expo, uint64_t seed, uint32_t counter,
-                         float cpu_share_floor, float *power_raw, float *probs, float *onehot, float *action_env,
-                         float *p_off01, float *action_store, risvec_stream_t stream);
+                         const float *tau, const uint8_t *hard, const float *eps, const float *expo, uint64_t seed,
+                         uint32_t counter, float cpu_share_floor, float *power_raw, float *probs, float *onehot,
+                         float *action_env, float *p_off01, float *action_store, risvec_stream_t stream);
 
 /* The two non-GEMM ends of PolicyNetwork.forward (sac_agent.py:62-78), all agents and envs per launch;
  * the fc1 x fc2 product in between is a plain batched GEMM (rocBLAS).  Row-major float32 everywhere.

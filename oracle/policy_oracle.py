@@ -51,8 +51,11 @@ def mask_logits(logits: np.ndarray, mask: Optional[np.ndarray]) -> np.ndarray:
 
 
 def choose_action(wts: Dict[str, np.ndarray], state: np.ndarray, mask: Optional[np.ndarray], tau: float,
-                  eps: np.ndarray, expo: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """SAC:187-225 -> (power_action [B,2], intent_probs [B,N], intent_onehot [B,N])."""
+                  eps: np.ndarray, expo: np.ndarray, hard: bool = False) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """SAC:187-225 -> (power_action [B,2], intent_probs [B,N], intent_onehot [B,N]).  `hard`: the
+    straight-through form `y_hard - y_soft + y_soft` of F.gumbel_softmax(hard=True) (SAC:110-113 with
+    `gumbel_hard`, switched on by the driver at TRAIN:1816-1818), evaluated in float32 like the reference
+    because its value IS the float32 rounding of that expression."""
     mu, log_std, logits = forward(wts, state)
     x_t = mu + np.exp(log_std) * np.asarray(eps, dtype=np.float64)        # Normal(mu, std).sample()
     power = np.tanh(x_t)
@@ -63,6 +66,9 @@ def choose_action(wts: Dict[str, np.ndarray], state: np.ndarray, mask: Optional[
     y = y / y.sum(-1, keepdims=True)
     onehot = np.zeros_like(y)
     onehot[np.arange(len(y)), y.argmax(-1)] = 1.0
+    if hard:
+        y32 = y.astype(np.float32)
+        y = ((onehot.astype(np.float32) - y32) + y32).astype(np.float64)
     return power, y, onehot
 
 

@@ -24,6 +24,7 @@ struct PolicyArgs {
     const float* heads;        // [V, E, 4 + V]
     const uint8_t* mask;       // [E, V, V] or NULL
     const float* tau;          // [V]
+    const uint8_t* hard;       // [V] or NULL: straight-through one-hot (F.gumbel_softmax(hard=True)) per agent
     const float* eps;          // [E, V, 2] or NULL
     const float* expo;         // [E, V, V] or NULL
     uint64_t seed;
@@ -84,8 +85,10 @@ k_policy_sample(PolicyArgs A) {
     }
     float sum = 0.0f;
     for (int k = 0; k < V; ++k) { const float t = expf(y[k] - zmax); y[k] = t; sum += t; }
+    const bool hard = A.hard && A.hard[v];
     for (int k = 0; k < V; ++k) {
-        const float pk = y[k] / sum;
+        float pk = y[k] / sum;
+        if (hard) pk = ((k == arg ? 1.0f : 0.0f) - pk) + pk;              // y_hard - y_soft + y_soft, in float32 (SAC:110-113)
         y[k] = pk;
         if (A.onehot) A.onehot[gid * V + k] = k == arg ? 1.0f : 0.0f;   // choose_action, SAC:215-216
         if (A.action_store) A.action_store[gid * (V + 2) + k] = k == v ? 0.0f : pk;   // TRAIN:1390, 1776-1784
@@ -448,10 +451,10 @@ hipError_t launch_policy_heads(int E, int V, int F, int H, const float* g, const
 }
 
 hipError_t launch_policy_sample(int E, int V, long long env_offset, const float* heads, const uint8_t* mask,
-                                const float* tau, const float* eps, const float* expo, uint64_t seed, uint32_t counter,
-                                float floor_eff, float* power_raw, float* probs, float* onehot, float* action_env,
-                                float* p_off01, float* action_store, hipStream_t st) {
-    PolicyArgs a{E, V, env_offset, heads, mask, tau, eps, expo, seed, counter, floor_eff, power_raw, probs, onehot,
+                                const float* tau, const uint8_t* hard, const float* eps, const float* expo, uint64_t seed,
+                                uint32_t counter, float floor_eff, float* power_raw, float* probs, float* onehot,
+                                float* action_env, float* p_off01, float* action_store, hipStream_t st) {
+    PolicyArgs a{E, V, env_offset, heads, mask, tau, hard, eps, expo, seed, counter, floor_eff, power_raw, probs, onehot,
                  action_env, p_off01, action_store};
     const long long n = (long long)E * V;
     hipLaunchKernelGGL(k_policy_sample, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a);

@@ -463,9 +463,9 @@ int risvec_marshal_actions(int32_t n_envs, int32_t n_veh, const float* power_raw
 }
 
 int risvec_policy_sample(int32_t n_envs, int32_t n_veh, int64_t env_offset, const float* heads, const uint8_t* mask,
-                         const float* tau, const float* eps, const float* expo, uint64_t seed, uint32_t counter,
-                         float cpu_share_floor, float* power_raw, float* probs, float* onehot, float* action_env,
-                         float* p_off01, float* action_store, risvec_stream_t stream) {
+                         const float* tau, const uint8_t* hard, const float* eps, const float* expo, uint64_t seed,
+                         uint32_t counter, float cpu_share_floor, float* power_raw, float* probs, float* onehot,
+                         float* action_env, float* p_off01, float* action_store, risvec_stream_t stream) {
     const char* fn = "risvec_policy_sample";
     if (n_envs < 1) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d must be >= 1", fn, n_envs);
     if (n_veh < 1 || n_veh > RISVEC_MAX_VEH)
@@ -476,7 +476,7 @@ int risvec_policy_sample(int32_t n_envs, int32_t n_veh, int64_t env_offset, cons
     OPT_PTR(mask, "mask"); OPT_PTR(eps, "eps"); OPT_PTR(expo, "expo"); OPT_PTR(onehot, "onehot");
     OPT_PTR(action_env, "action_env"); OPT_PTR(p_off01, "p_off01"); OPT_PTR(action_store, "action_store");
     const float fl = cpu_share_floor < 0.0f ? 0.0f : (cpu_share_floor > 0.95f ? 0.95f : cpu_share_floor);
-    return finish(fn, risvec::launch_policy_sample(n_envs, n_veh, env_offset, heads, mask, tau, eps, expo, seed, counter,
+    return finish(fn, risvec::launch_policy_sample(n_envs, n_veh, env_offset, heads, mask, tau, hard, eps, expo, seed, counter,
                                                    fl, power_raw, probs, onehot, action_env, p_off01, action_store,
                                                    (hipStream_t)stream));
 }

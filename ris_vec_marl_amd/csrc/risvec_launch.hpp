@@ -62,9 +62,9 @@ hipError_t launch_marshal_actions(int E, int V, const float* power_raw, const fl
                                   float* action_env, float* p_off01, float* action_store, hipStream_t st);
 
 hipError_t launch_policy_sample(int E, int V, long long env_offset, const float* heads, const uint8_t* mask,
-                                const float* tau, const float* eps, const float* expo, uint64_t seed, uint32_t counter,
-                                float floor_eff, float* power_raw, float* probs, float* onehot, float* action_env,
-                                float* p_off01, float* action_store, hipStream_t st);
+                                const float* tau, const uint8_t* hard, const float* eps, const float* expo, uint64_t seed,
+                                uint32_t counter, float floor_eff, float* power_raw, float* probs, float* onehot,
+                                float* action_env, float* p_off01, float* action_store, hipStream_t st);
 
 hipError_t launch_policy_layer1(int E, int V, int IN, int F, const float* obs, const float* W1, const float* b1,
                                 const float* lw, const float* lb, float* out, hipStream_t st);

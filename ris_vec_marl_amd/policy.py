@@ -53,6 +53,7 @@ class BatchedPolicy:
         self.ln1_w, self.ln1_b = torch.ones(V, 1, fc1_dims, device=dev), torch.zeros(V, 1, fc1_dims, device=dev)
         self.ln2_w, self.ln2_b = torch.ones(V, 1, fc2_dims, device=dev), torch.zeros(V, 1, fc2_dims, device=dev)
         self.tau = torch.full((V,), 2.0, device=dev)                                    # SAC:54 (annealed by the driver)
+        self.gumbel_hard = torch.zeros(V, dtype=torch.uint8, device=dev)                # SAC:56, per agent
 
     # ------------------------------------------------------------------ weights
     def load_agent_state_dict(self, agent: int, sd: Mapping[str, object]) -> None:
@@ -69,9 +70,12 @@ class BatchedPolicy:
         if "tau" in sd:
             self.tau[a] = float(torch.as_tensor(sd["tau"]))
 
-    def set_tau(self, tau: float) -> None:
-        """The driver's temperature annealing (TRAIN:1804-1815 sets every agent's `policy.tau`; the optional hard straight-through mode of TRAIN:1816-1818, off by default, is not built)."""
+    def set_tau(self, tau: float, gumbel_hard: bool = False) -> None:
+        """The driver's temperature annealing (TRAIN:1804-1815 sets every agent's `policy.tau`) and its
+        switch to the straight-through one-hot form (TRAIN:1816-1818: `want_hard and cur_tau <= 0.3`;
+        pass the resulting boolean)."""
         self.tau.fill_(float(tau))
+        self.gumbel_hard.fill_(1 if gumbel_hard else 0)
 
     # ------------------------------------------------------------------ forward
     def forward_heads(self, obs: torch.Tensor) -> torch.Tensor:
@@ -134,14 +138,15 @@ class BatchedPolicy:
         a_store = torch.empty(E, V * (V + 2), device=dev) if marsh else None
         self._calls += 1
         N.check(N.load().risvec_policy_sample(
-            E, V, self.env_offset, heads.data_ptr(), _ptr(mk), self.tau.data_ptr(), _ptr(ep), _ptr(ex), self.seed,
+            E, V, self.env_offset, heads.data_ptr(), _ptr(mk), self.tau.data_ptr(), self.gumbel_hard.data_ptr(), _ptr(ep),
+            _ptr(ex), self.seed,
             self._calls, float(cpu_share_floor) if marsh else 0.0, power.data_ptr(), probs.data_ptr(), _ptr(onehot),
             _ptr(a_env), _ptr(p01), _ptr(a_store), torch.cuda.current_stream(dev).cuda_stream))
         out = (power, probs, onehot)
         return out + (a_env, p01, a_store) if marsh else out
 
     # ------------------------------------------------------------------ checkpoint
-    _KEYS = ("W1", "b1", "W2", "b2", "Wh", "bh", "ln1_w", "ln1_b", "ln2_w", "ln2_b", "tau")
+    _KEYS = ("W1", "b1", "W2", "b2", "Wh", "bh", "ln1_w", "ln1_b", "ln2_w", "ln2_b", "tau", "gumbel_hard")
 
     def state_dict(self) -> dict:
         return {k: getattr(self, k).detach().cpu().clone() for k in self._KEYS}

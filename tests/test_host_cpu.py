@@ -252,10 +252,10 @@ def test_noma_config_reads_the_drivers_yaml_keys():
 
 def test_policy_abi_without_a_gpu():
     lib = N.load()
-    assert lib.risvec_policy_sample(0, 8, 0, None, None, None, None, None, 0, 0, 0.1, None, None, None, None, None, None,
-                                    None) == N.ERR_SHAPE
-    assert lib.risvec_policy_sample(4, 8, 0, None, None, None, None, None, 0, 0, 0.1, None, None, None, None, None, None,
-                                    None) == N.ERR_ARG
+    assert lib.risvec_policy_sample(0, 8, 0, None, None, None, None, None, None, 0, 0, 0.1, None, None, None, None, None,
+                                    None, None) == N.ERR_SHAPE
+    assert lib.risvec_policy_sample(4, 8, 0, None, None, None, None, None, None, 0, 0, 0.1, None, None, None, None, None,
+                                    None, None) == N.ERR_ARG
     assert lib.risvec_policy_layer1(4, 8, 5, 4096, None, None, None, None, None, None, None) == N.ERR_SHAPE
     assert b"f1" in lib.risvec_last_error()
     assert lib.risvec_policy_layer1(4, 8, 5, 512, None, None, None, None, None, None, None) == N.ERR_ARG

@@ -40,6 +40,7 @@ def test_vs_golden(path):
     for a in range(V):
         pol.load_agent_state_dict(a, agent_weights(d, a))
         pol.tau[a] = float(d["tau"][a])
+        pol.gumbel_hard[a] = int(d["hard"][a])
     obs = np.stack([d["state"][a] for a in range(V)], 1)                      # [B,V,5]
     mask = np.stack([d["mask"][a] if d["has_mask"][a] else np.ones((B, V), np.float32) for a in range(V)], 1)
     eps = np.stack([d["eps"][a] for a in range(V)], 1)
@@ -52,9 +53,15 @@ def test_vs_golden(path):
     power, probs, onehot, a_env, p01, a_store = pol.choose_action(T(obs), T(mask), T(eps), T(expo), cpu_share_floor=0.1)
     for a in range(V):
         np.testing.assert_allclose(power.cpu().numpy()[:, a], d["power"][a], atol=2e-5)
-        np.testing.assert_allclose(probs.cpu().numpy()[:, a], d["probs"][a], atol=2e-5)
-        clear = PO.top2_gap(d["probs"][a]) > 1e-4
+        w = agent_weights(d, a)
+        soft = PO.choose_action(w, d["state"][a], d["mask"][a] if d["has_mask"][a] else None, float(d["tau"][a]),
+                                d["eps"][a], d["expo"][a])[1]
+        clear = PO.top2_gap(soft) > 1e-4
         assert np.array_equal(onehot.cpu().numpy()[:, a][clear], d["onehot"][a][clear])
+        if d["hard"][a]:                      # straight-through: the one-hot up to one float32 rounding
+            np.testing.assert_allclose(probs.cpu().numpy()[:, a][clear], d["probs"][a][clear], atol=2e-7)
+        else:
+            np.testing.assert_allclose(probs.cpu().numpy()[:, a], d["probs"][a], atol=2e-5)
     m_env, m_p01, m_store = marshal_actions(power, probs, 0.1)               # fused marshalling == separate launch
     assert torch.equal(a_env, m_env) and torch.equal(p01, m_p01) and torch.equal(a_store, m_store)
 

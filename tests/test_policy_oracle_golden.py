@@ -29,12 +29,18 @@ def test_choose_action(path):
         np.testing.assert_allclose(log_std, d["log_std"][a], atol=2e-6)
         np.testing.assert_allclose(logits, d["logits"][a], atol=2e-6)
         mask = d["mask"][a] if d["has_mask"][a] else None
-        power, y, onehot = PO.choose_action(w, d["state"][a], mask, float(d["tau"][a]), d["eps"][a], d["expo"][a])
+        hard = bool(d["hard"][a])
+        power, y, onehot = PO.choose_action(w, d["state"][a], mask, float(d["tau"][a]), d["eps"][a], d["expo"][a], hard)
         np.testing.assert_allclose(power, d["power"][a], atol=1e-5)
-        np.testing.assert_allclose(y, d["probs"][a], atol=1e-5)
-        clear = PO.top2_gap(d["probs"][a]) > 1e-4
+        soft = PO.choose_action(w, d["state"][a], mask, float(d["tau"][a]), d["eps"][a], d["expo"][a])[1]
+        clear = PO.top2_gap(soft) > 1e-4
         assert clear.mean() > 0.9
         assert np.array_equal(onehot[clear], d["onehot"][a][clear])
+        if hard:                                      # straight-through: one-hot up to one float32 rounding
+            np.testing.assert_allclose(y[clear], d["probs"][a][clear], atol=2e-7)
+            assert np.array_equal(np.round(d["probs"][a]), d["onehot"][a])
+            continue
+        np.testing.assert_allclose(y, d["probs"][a], atol=1e-5)
         if mask is not None:                          # blocked users get (numerically) zero probability,
             m = mask.copy(); m[m.sum(-1) == 0] = 1     # except on the all-zero row the reference opens up
             assert np.all(y[m <= 0] < 1e-30)

@@ -34,7 +34,7 @@ def capture(tag, V, fc1, fc2, B, seed):
     rng = np.random.default_rng(seed)
     tmp = tempfile.mkdtemp(prefix="risvec_policy_")          # the constructor creates its checkpoint dir
     rec = dict(state=[], mask=[], has_mask=[], tau=[], eps=[], expo=[], power=[], probs=[], onehot=[], mu=[],
-               log_std=[], logits=[])
+               log_std=[], logits=[], hard=[])
     weights = {}
     for a in range(V):
         net = REF.PolicyNetwork(3e-4, 5, fc1, fc2, 2, V, name="policy", agent_label=a, chkpt_dir=tmp)
@@ -49,6 +49,8 @@ def capture(tag, V, fc1, fc2, B, seed):
         net.tau.fill_(tau)
         state = torch.from_numpy(rng.uniform(0, 1.2, (B, 5)).astype(np.float32))
         has_mask = a % 3 != 2
+        hard = a % 4 == 3                                       # straight-through one-hot (driver: tau <= 0.3 and gumbel_hard)
+        net.gumbel_hard = hard
         mask = torch.from_numpy((rng.uniform(size=(B, V)) < 0.6).astype(np.float32))
         mask[0] = 0.0                                           # an all-zero row: the reference opens it up
         net.eval()
@@ -68,13 +70,16 @@ def capture(tag, V, fc1, fc2, B, seed):
                 m[m.sum(-1) == 0] = 1.0
                 ml = logits.masked_fill(m <= 0, torch.finfo(logits.dtype).min / 2)
             y2 = ((ml + -expo.log()) / tau).softmax(-1)
+            if hard:                                            # F.gumbel_softmax(hard=True): y_hard - y_soft + y_soft
+                y_hard = torch.zeros_like(y2).scatter_(-1, y2.max(-1, keepdim=True)[1], 1.0)
+                y2 = y_hard - y2 + y2
             assert torch.equal(torch.tanh(x_t), power), "normal draws not reproduced"
             assert torch.equal(y2, y), "gumbel draws not reproduced"
             onehot = F.one_hot(torch.argmax(y, -1), num_classes=V).float()      # choose_action, :215-216
         for k, v in net.state_dict().items():
             if k != "tau":
                 weights["a%d.%s" % (a, k)] = v.numpy().copy()
-        for k, v in dict(state=state, mask=mask, has_mask=has_mask, tau=tau, eps=eps, expo=expo, power=power, probs=y,
+        for k, v in dict(state=state, mask=mask, has_mask=has_mask, hard=hard, tau=tau, eps=eps, expo=expo, power=power, probs=y,
                          onehot=onehot, mu=mu, log_std=log_std, logits=logits).items():
             rec[k].append(v.numpy() if hasattr(v, "numpy") else v)
     np.savez_compressed(os.path.join(OUT_DIR, "policy_%s.npz" % tag), V=V, fc1=fc1, fc2=fc2, B=B,
