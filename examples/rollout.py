@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""The reference driver's rollout loop (marl_train_bcd.py:1244-1830, without the learner) with every
+stage on the GPU: batched SAC policies -> NOMA pairing -> fused RIS gains + step() -> replay ring.
+
+    python examples/rollout.py [n_envs] [episodes]
+
+Everything between the policy weights and the sampled training batch stays in HBM; the only host work
+per step is four kernel launches.  Needs an MI355X and the built librisvec.so."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ris_vec_marl_amd import (BatchedPolicy, NomaGrouper, VecEnviron, VecReplayBuffer, apply_yaml_config,  # noqa: E402
+                              reference_lanes)
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+EPISODES = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+V, M, N_STEP, RIS_EVERY = 8, 40, 100, 100            # Config defaults of the driver (n_veh, M, steps, K_STEPS)
+
+L = reference_lanes()
+env = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3,
+                 n_envs=E, device="cuda:0", seed=0)
+apply_yaml_config(env, None)                        # or load_yaml("config.yaml")
+env.make_new_game()
+policy = BatchedPolicy(V, 5, 512, 256, device="cuda:0")          # policy.load_agent_state_dict(i, sd) for trained weights
+grouper = NomaGrouper(env)
+memory = VecReplayBuffer(8 * N_STEP * E, 5, V + 2, V, device="cuda:0")
+
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for ep in range(EPISODES):
+    env.begin_episode(ep, env_refresh_every=5)
+    grouper.begin_episode(ep)
+    state_old = env.observe().clone()
+    mask = None
+    for st in range(N_STEP):
+        refreshed = env.begin_step(st, ris_every=RIS_EVERY)       # BCD sweep + gains on refresh steps
+        if refreshed:
+            mask = grouper.refresh_mask()
+        _, _, _, action_env, p_off01, action_store = policy.choose_action(state_old, mask, cpu_share_floor=env.cpu_share_floor,
+                                                                          want_onehot=False)
+        partner, n_groups = grouper.group(p_off01, st)
+        env.step(action_env, partner, n_groups)
+        memory.store_batch(state_old, action_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"],
+                           done=(st == N_STEP - 1), mask=mask if refreshed else None)
+        state_old.copy_(env.tensors["obs"])
+    batch = memory.sample_buffer(256)               # what global_learn would consume
+    g = env.tensors["metrics"][:, 0]
+    print("episode %d: mean global reward %.3f, pairs/env %.2f, replay rows %d"
+          % (ep, float(g.mean()), float(V - grouper._t["n_groups"].float().mean()), min(memory.mem_cntr, memory.mem_size)))
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("%.2e env-steps/s over %d envs x %d steps" % (E * EPISODES * N_STEP / dt, E, EPISODES * N_STEP))

@@ -38,6 +38,9 @@ struct PolicyArgs {
     float* action_store;       // [E, V, V + 2] or NULL
 };
 
+// VR > 0: the V <= VR logits of a row live in registers (fully unrolled loops); VR = 0: any V, the
+// probs row in global memory doubles as scratch.
+template <int VR>
 __global__ void __launch_bounds__(kBlock)
 k_policy_sample(PolicyArgs A) {
     const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -67,10 +70,16 @@ k_policy_sample(PolicyArgs A) {
     const float neg_large = -FLT_MAX / 2.0f;             // torch.finfo(float32).min / 2  (SAC:103)
     const float tau_v = A.tau[v];
     float* y = A.probs + gid * V;
+    float zr[VR > 0 ? VR : 1];
+    auto put = [&](int k, float val) { if constexpr (VR > 0) zr[k] = val; else y[k] = val; };
+    auto get = [&](int k) { if constexpr (VR > 0) return zr[k]; else return y[k]; };
+    const int KN = VR > 0 ? VR : V;
     float zmax = -INFINITY;
     int arg = 0;
     uint4 r = make_uint4(0, 0, 0, 0);
-    for (int k = 0; k < V; ++k) {
+#pragma unroll (VR > 0 ? VR : 1)
+    for (int k = 0; k < KN; ++k) {
+        if (VR > 0 && k >= V) break;
         float ex;
         if (A.expo) ex = A.expo[gid * V + k];
         else {
@@ -80,14 +89,22 @@ k_policy_sample(PolicyArgs A) {
         }
         const float ml = (use_mask && mrow[k] == 0) ? neg_large : h[4 + k];
         const float z = (ml + -logf(ex)) / tau_v;                     // (logits + gumbel) / tau
-        y[k] = z;
+        put(k, z);
         if (z > zmax) { zmax = z; arg = k; }
     }
     float sum = 0.0f;
-    for (int k = 0; k < V; ++k) { const float t = expf(y[k] - zmax); y[k] = t; sum += t; }
+#pragma unroll (VR > 0 ? VR : 1)
+    for (int k = 0; k < KN; ++k) {
+        if (VR > 0 && k >= V) break;
+        const float t = expf(get(k) - zmax);
+        put(k, t);
+        sum += t;
+    }
     const bool hard = A.hard && A.hard[v];
-    for (int k = 0; k < V; ++k) {
-        float pk = y[k] / sum;
+#pragma unroll (VR > 0 ? VR : 1)
+    for (int k = 0; k < KN; ++k) {
+        if (VR > 0 && k >= V) break;
+        float pk = get(k) / sum;
         if (hard) pk = ((k == arg ? 1.0f : 0.0f) - pk) + pk;              // y_hard - y_soft + y_soft, in float32 (SAC:110-113)
         y[k] = pk;
         if (A.onehot) A.onehot[gid * V + k] = k == arg ? 1.0f : 0.0f;   // choose_action, SAC:215-216
@@ -457,7 +474,10 @@ hipError_t launch_policy_sample(int E, int V, long long env_offset, const float*
     PolicyArgs a{E, V, env_offset, heads, mask, tau, hard, eps, expo, seed, counter, floor_eff, power_raw, probs, onehot,
                  action_env, p_off01, action_store};
     const long long n = (long long)E * V;
-    hipLaunchKernelGGL(k_policy_sample, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a);
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    if (V <= 8) hipLaunchKernelGGL(k_policy_sample<8>, grid, dim3(kBlock), 0, st, a);
+    else if (V <= 16) hipLaunchKernelGGL(k_policy_sample<16>, grid, dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL(k_policy_sample<0>, grid, dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }
 
