@@ -74,10 +74,11 @@ k_policy_sample(PolicyArgs A) {
     auto put = [&](int k, float val) { if constexpr (VR > 0) zr[k] = val; else y[k] = val; };
     auto get = [&](int k) { if constexpr (VR > 0) return zr[k]; else return y[k]; };
     const int KN = VR > 0 ? VR : V;
+    constexpr int kUnroll = VR > 0 ? VR : 1;
     float zmax = -INFINITY;
     int arg = 0;
     uint4 r = make_uint4(0, 0, 0, 0);
-#pragma unroll (VR > 0 ? VR : 1)
+#pragma unroll kUnroll
     for (int k = 0; k < KN; ++k) {
         if (VR > 0 && k >= V) break;
         float ex;
@@ -93,7 +94,7 @@ k_policy_sample(PolicyArgs A) {
         if (z > zmax) { zmax = z; arg = k; }
     }
     float sum = 0.0f;
-#pragma unroll (VR > 0 ? VR : 1)
+#pragma unroll kUnroll
     for (int k = 0; k < KN; ++k) {
         if (VR > 0 && k >= V) break;
         const float t = expf(get(k) - zmax);
@@ -101,7 +102,7 @@ k_policy_sample(PolicyArgs A) {
         sum += t;
     }
     const bool hard = A.hard && A.hard[v];
-#pragma unroll (VR > 0 ? VR : 1)
+#pragma unroll kUnroll
     for (int k = 0; k < KN; ++k) {
         if (VR > 0 && k >= V) break;
         float pk = get(k) / sum;
