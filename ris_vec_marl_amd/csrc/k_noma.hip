@@ -245,7 +245,11 @@ struct MatchTab {
 
 // Value and choice of the recurrence at `mask` (TRAIN:360-391): the lowest unused user x stays single
 // (arg -1) or takes partner j (arg j); arg -2 = no option (value 0, nothing below it).
-__device__ __forceinline__ double best_at(const MatchTab& M, const double* w, bool singles, int mask, int& arg) {
+// `adj[x]`: bit j set when (x, j), j > x, is an admissible edge -- the partners are walked in increasing j
+// by peeling set bits, so a sparse graph (the usual case: only the top-quantile edges survive) costs a
+// couple of iterations per state instead of one per user.
+__device__ __forceinline__ double best_at(const MatchTab& M, const double* w, const int* adj, bool singles, int mask,
+                                          int& arg) {
     const int x = __ffs(~mask) - 1;
     double best = -kInf;
     arg = -2;
@@ -253,10 +257,9 @@ __device__ __forceinline__ double best_at(const MatchTab& M, const double* w, bo
         const double w1 = M.value(mask | (1 << x));
         if (w1 > best) { best = w1; arg = -1; }
     }
-    for (int j = x + 1; j < M.K; ++j) {
-        if ((mask >> j) & 1) continue;
+    for (unsigned cand = (unsigned)adj[x] & ~(unsigned)mask; cand; cand &= cand - 1) {
+        const int j = __ffs(cand) - 1;
         const double we = w[x * kNV + j];
-        if (!finite(we)) continue;
         const double w2 = M.value(mask | (1 << x) | (1 << j));
         if (finite(w2) && we + w2 > best) { best = we + w2; arg = j; }
     }
@@ -278,7 +281,7 @@ k_noma_group(NomaArgs A) {
     __shared__ double s_dp[S::DP];
     __shared__ float s_hist[S::NN];
     __shared__ uint8_t s_feas[S::NN], s_qos[S::NN];
-    __shared__ int s_part[kNV], s_base[kNV + 1], s_binom[16 * kBinW], s_sizeoff[16 * (kBinW + 1)];
+    __shared__ int s_part[kNV], s_base[kNV + 1], s_adj[kNV], s_binom[16 * kBinW], s_sizeoff[16 * (kBinW + 1)];
     __shared__ signed char s_arg[S::DP];               // choice taken at each state, for the walk-back
     constexpr bool kRanked = NMAX > S::KPLAIN;         // more users than the plain 2^K table can hold?
     __shared__ uint16_t s_clo[kRanked ? 256 : 1], s_chi[kRanked ? 9 * 128 : 1];   // colex-rank lookup
@@ -447,6 +450,12 @@ k_noma_group(NomaArgs A) {
                         }
                         s_w[a * kNV + b] = a < b ? s_W[va * N + vb] : -kInf;
                     }
+                    __syncthreads();
+                    if (lane < K) {                             // admissible partners above each user
+                        int bits = 0;
+                        for (int b = lane + 1; b < K; ++b) bits |= finite(s_w[lane * kNV + b]) ? (1 << b) : 0;
+                        s_adj[lane] = bits;
+                    }
                     if (lane == 0) {
                         int off = 0;
                         for (int x = 0; x < K; ++x) {
@@ -464,7 +473,7 @@ k_noma_group(NomaArgs A) {
                             if (__popc(T) > x) continue;         // not reachable
                             const int m = low | (T << (x + 1));
                             int arg;
-                            const double b = best_at(MT, s_w, singles, m, arg);
+                            const double b = best_at(MT, s_w, s_adj, singles, m, arg);
                             const int sl = MT.slot(m);
                             s_dp[sl] = arg == -2 ? 0.0 : b;            // TRAIN:389-390
                             s_arg[sl] = (signed char)arg;
