@@ -7,7 +7,7 @@
 //   logits incl. the all-zero-row rule (SAC:91-104), the soft Gumbel-softmax (SAC:110-113), the arg-max
 //   one-hot of choose_action (SAC:215-216), and -- optionally -- the env action, pairing power and replay
 //   action row of TRAIN:1386-1396, 1601-1608, 1776-1784 (what k_marshal_* would do in a second launch).
-// Draws are injected (parity) or Philox.  One lane per (env, agent); V <= 64.
+// Draws are injected (parity) or Philox.  pow2ceil(V) lanes per (env, agent) row; V <= 64.
 #include <cfloat>
 
 #include "risvec_launch.hpp"
@@ -38,91 +38,86 @@ struct PolicyArgs {
     float* action_store;       // [E, V, V + 2] or NULL
 };
 
-// VR > 0: the V <= VR logits of a row live in registers (fully unrolled loops); VR = 0: any V, the
-// probs row in global memory doubles as scratch.
-template <int VR>
+// VP = pow2ceil(V) lanes per (env, agent) row, 64 / VP rows per wavefront: lane k owns logit k, so the
+// heads / draws / mask rows are read and the probability rows written with consecutive lanes on consecutive
+// words; max / arg-max / sum over a row are log2(VP) DPP exchanges.  Lane 0 of a row also owns the power head.
+template <int VP>
 __global__ void __launch_bounds__(kBlock)
 k_policy_sample(PolicyArgs A) {
-    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int V = A.V, H = 4 + V;
-    if (gid >= (long long)A.E * V) return;
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long row_raw = t / VP, n_rows = (long long)A.E * V;
+    const int k = (int)(t % VP);
+    const bool live_row = row_raw < n_rows;
+    const long long gid = live_row ? row_raw : n_rows - 1;     // dead lanes shadow the last row, store nothing
+    const bool mine = live_row && k < V;
     const long long e = gid / V;
     const int v = (int)(gid % V);
     const float* h = A.heads + ((long long)v * A.E + e) * H;
     const uint32_t genv = (uint32_t)(A.env_offset + e);
-    // ---- continuous head: x = mu + std * eps, power = tanh(x)  (SAC:72, 83-86) ------------------------
-    float e0, e1;
-    if (A.eps) { e0 = A.eps[gid * 2]; e1 = A.eps[gid * 2 + 1]; }
-    else {
-        const uint4 r = philox4x32_10(genv, (uint32_t)v, A.counter, kSitePolicyEps, A.seed);
-        const float2 n = normal2(r.x, r.y);
-        e0 = n.x; e1 = n.y;
-    }
-    const float ls0 = fminf(fmaxf(h[2], -20.0f), 2.0f), ls1 = fminf(fmaxf(h[3], -20.0f), 2.0f);
-    const float p0 = tanhf(e0 * expf(ls0) + h[0]), p1 = tanhf(e1 * expf(ls1) + h[1]);
-    A.power_raw[gid * 2] = p0;
-    A.power_raw[gid * 2 + 1] = p1;
-    // ---- discrete head: masked logits, soft Gumbel-softmax  (SAC:91-113) -------------------------------
-    const uint8_t* mrow = A.mask ? A.mask + gid * V : nullptr;
-    bool any_open = false;
-    if (mrow) for (int k = 0; k < V; ++k) any_open = any_open || mrow[k] != 0;
-    const bool use_mask = mrow && any_open;              // an all-zero row is opened up (SAC:97-100)
-    const float neg_large = -FLT_MAX / 2.0f;             // torch.finfo(float32).min / 2  (SAC:103)
-    const float tau_v = A.tau[v];
-    float* y = A.probs + gid * V;
-    float zr[VR > 0 ? VR : 1];
-    auto put = [&](int k, float val) { if constexpr (VR > 0) zr[k] = val; else y[k] = val; };
-    auto get = [&](int k) { if constexpr (VR > 0) return zr[k]; else return y[k]; };
-    const int KN = VR > 0 ? VR : V;
-    constexpr int kUnroll = VR > 0 ? VR : 1;
-    float zmax = -INFINITY;
-    int arg = 0;
-    uint4 r = make_uint4(0, 0, 0, 0);
-#pragma unroll kUnroll
-    for (int k = 0; k < KN; ++k) {
-        if (VR > 0 && k >= V) break;
+    // ---- discrete head: masked logits, Gumbel-softmax  (SAC:91-113) --------------------------------------
+    const bool open_k = k < V && (!A.mask || A.mask[gid * V + k] != 0);
+    const bool any_open = gsum<VP>(A.mask && open_k ? 1.0f : 0.0f) > 0.0f;
+    const bool blocked = A.mask && any_open && !open_k;        // an all-zero row is opened up (SAC:97-100)
+    float z = -INFINITY;
+    if (k < V) {
         float ex;
         if (A.expo) ex = A.expo[gid * V + k];
         else {
-            if ((k & 3) == 0) r = philox4x32_10(genv, (uint32_t)v, A.counter, kSitePolicyGumbel + 0x100u * (k >> 2), A.seed);
+            const uint4 r = philox4x32_10(genv, (uint32_t)v, A.counter, kSitePolicyGumbel + 0x100u * (k >> 2), A.seed);
             const uint32_t x = (k & 3) == 0 ? r.x : (k & 3) == 1 ? r.y : (k & 3) == 2 ? r.z : r.w;
             ex = -logf(((float)(x >> 8) + 1.0f) * 0x1p-24f);          // Exp(1), u in (0, 1]
         }
-        const float ml = (use_mask && mrow[k] == 0) ? neg_large : h[4 + k];
-        const float z = (ml + -logf(ex)) / tau_v;                     // (logits + gumbel) / tau
-        put(k, z);
-        if (z > zmax) { zmax = z; arg = k; }
+        const float ml = blocked ? -FLT_MAX / 2.0f : h[4 + k];        // torch.finfo(float32).min / 2  (SAC:103)
+        z = (ml + -logf(ex)) / A.tau[v];                              // (logits + gumbel) / tau
     }
-    float sum = 0.0f;
-#pragma unroll kUnroll
-    for (int k = 0; k < KN; ++k) {
-        if (VR > 0 && k >= V) break;
-        const float t = expf(get(k) - zmax);
-        put(k, t);
-        sum += t;
+    float zmax = z;
+    int arg = k < V ? k : 0x7fffffff;
+#pragma unroll
+    for (int o = 1; o < VP; o <<= 1) {                                // arg-max, first index on ties
+        float oz; int oa;
+        if (o == 1) { oz = xchg<1>(zmax); oa = __builtin_bit_cast(int, xchg<1>(__builtin_bit_cast(float, arg))); }
+        else if (o == 2) { oz = xchg<2>(zmax); oa = __builtin_bit_cast(int, xchg<2>(__builtin_bit_cast(float, arg))); }
+        else if (o == 4) { oz = xchg<4>(zmax); oa = __builtin_bit_cast(int, xchg<4>(__builtin_bit_cast(float, arg))); }
+        else if (o == 8) { oz = xchg<8>(zmax); oa = __builtin_bit_cast(int, xchg<8>(__builtin_bit_cast(float, arg))); }
+        else if (o == 16) { oz = xchg<16>(zmax); oa = __builtin_bit_cast(int, xchg<16>(__builtin_bit_cast(float, arg))); }
+        else { oz = xchg<32>(zmax); oa = __builtin_bit_cast(int, xchg<32>(__builtin_bit_cast(float, arg))); }
+        if (oz > zmax || (oz == zmax && oa < arg)) { zmax = oz; arg = oa; }
     }
-    const bool hard = A.hard && A.hard[v];
-#pragma unroll kUnroll
-    for (int k = 0; k < KN; ++k) {
-        if (VR > 0 && k >= V) break;
-        float pk = get(k) / sum;
-        if (hard) pk = ((k == arg ? 1.0f : 0.0f) - pk) + pk;              // y_hard - y_soft + y_soft, in float32 (SAC:110-113)
-        y[k] = pk;
-        if (A.onehot) A.onehot[gid * V + k] = k == arg ? 1.0f : 0.0f;   // choose_action, SAC:215-216
+    const float ez = k < V ? expf(z - zmax) : 0.0f;
+    const float sum = gsum<VP>(ez);
+    float pk = ez / sum;
+    if (A.hard && A.hard[v]) pk = ((k == arg ? 1.0f : 0.0f) - pk) + pk;   // y_hard - y_soft + y_soft (SAC:110-113)
+    if (mine) {
+        A.probs[gid * V + k] = pk;
+        if (A.onehot) A.onehot[gid * V + k] = k == arg ? 1.0f : 0.0f;     // choose_action, SAC:215-216
         if (A.action_store) A.action_store[gid * (V + 2) + k] = k == v ? 0.0f : pk;   // TRAIN:1390, 1776-1784
     }
-    // ---- marshalling (optional)  TRAIN:1391-1396, 1601-1608 ---------------------------------------------
-    if (A.action_store) {
-        A.action_store[gid * (V + 2) + V] = p0;
-        A.action_store[gid * (V + 2) + V + 1] = p1;
+    // ---- continuous head + marshalling, lane 0 of the row  (SAC:72, 83-86; TRAIN:1391-1396, 1601-1608) ---
+    if (live_row && k == 0) {
+        float e0, e1;
+        if (A.eps) { e0 = A.eps[gid * 2]; e1 = A.eps[gid * 2 + 1]; }
+        else {
+            const uint4 r = philox4x32_10(genv, (uint32_t)v, A.counter, kSitePolicyEps, A.seed);
+            const float2 n = normal2(r.x, r.y);
+            e0 = n.x; e1 = n.y;
+        }
+        const float ls0 = fminf(fmaxf(h[2], -20.0f), 2.0f), ls1 = fminf(fmaxf(h[3], -20.0f), 2.0f);
+        const float p0 = tanhf(e0 * expf(ls0) + h[0]), p1 = tanhf(e1 * expf(ls1) + h[1]);
+        A.power_raw[gid * 2] = p0;
+        A.power_raw[gid * 2 + 1] = p1;
+        if (A.action_store) {
+            A.action_store[gid * (V + 2) + V] = p0;
+            A.action_store[gid * (V + 2) + V + 1] = p1;
+        }
+        const float m0 = (fminf(fmaxf(p0, -0.999f), 0.999f) + 1.0f) / 2.0f;
+        const float m1 = (fminf(fmaxf(p1, -0.999f), 0.999f) + 1.0f) / 2.0f;
+        if (A.action_env) {
+            A.action_env[(e * 2 + 0) * V + v] = m0;
+            A.action_env[(e * 2 + 1) * V + v] = fmaxf(m1, A.floor_eff);
+        }
+        if (A.p_off01) A.p_off01[gid] = m0;
     }
-    const float m0 = (fminf(fmaxf(p0, -0.999f), 0.999f) + 1.0f) / 2.0f;
-    const float m1 = (fminf(fmaxf(p1, -0.999f), 0.999f) + 1.0f) / 2.0f;
-    if (A.action_env) {
-        A.action_env[(e * 2 + 0) * V + v] = m0;
-        A.action_env[(e * 2 + 1) * V + v] = fmaxf(m1, A.floor_eff);
-    }
-    if (A.p_off01) A.p_off01[gid] = m0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,11 +469,18 @@ hipError_t launch_policy_sample(int E, int V, long long env_offset, const float*
                                 float* action_env, float* p_off01, float* action_store, hipStream_t st) {
     PolicyArgs a{E, V, env_offset, heads, mask, tau, hard, eps, expo, seed, counter, floor_eff, power_raw, probs, onehot,
                  action_env, p_off01, action_store};
-    const long long n = (long long)E * V;
+    const int vp = pow2_ceil(V);
+    const long long n = (long long)E * V * vp;
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-    if (V <= 8) hipLaunchKernelGGL(k_policy_sample<8>, grid, dim3(kBlock), 0, st, a);
-    else if (V <= 16) hipLaunchKernelGGL(k_policy_sample<16>, grid, dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL(k_policy_sample<0>, grid, dim3(kBlock), 0, st, a);
+    switch (vp) {
+        case 1: hipLaunchKernelGGL(k_policy_sample<1>, grid, dim3(kBlock), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(k_policy_sample<2>, grid, dim3(kBlock), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(k_policy_sample<4>, grid, dim3(kBlock), 0, st, a); break;
+        case 8: hipLaunchKernelGGL(k_policy_sample<8>, grid, dim3(kBlock), 0, st, a); break;
+        case 16: hipLaunchKernelGGL(k_policy_sample<16>, grid, dim3(kBlock), 0, st, a); break;
+        case 32: hipLaunchKernelGGL(k_policy_sample<32>, grid, dim3(kBlock), 0, st, a); break;
+        default: hipLaunchKernelGGL(k_policy_sample<64>, grid, dim3(kBlock), 0, st, a); break;
+    }
     return hipGetLastError();
 }
 

@@ -66,13 +66,15 @@ def test_vs_golden(path):
     assert torch.equal(a_env, m_env) and torch.equal(p01, m_p01) and torch.equal(a_store, m_store)
 
 
-def test_reference_sized_networks_vs_oracle():
-    """The driver's sizes (512 / 256 hidden, config A_fc1_dims / A_fc2_dims), 8 agents, E = 1 024, random
-    weights in the reference's init ranges: device float32 vs the float64 oracle."""
+@pytest.mark.parametrize("shape", [(8, 512, 256, 1024), (5, 64, 32, 300), (16, 128, 64, 300), (11, 32, 32, 200), (1, 16, 8, 50)])
+def test_reference_sized_networks_vs_oracle(shape):
+    """The driver's sizes (512 / 256 hidden, config A_fc1_dims / A_fc2_dims), 8 agents, E = 1 024 -- and
+    agent counts that are not powers of two (padding lanes in the row-per-lane-group sampling kernel) --
+    random weights in the reference's init ranges: device float32 vs the float64 oracle."""
     from ris_vec_marl_amd import BatchedPolicy
-    V, E = 8, 1024
+    V, F1, F2, E = shape
     rng = np.random.default_rng(3)
-    pol = BatchedPolicy(V, 5, 512, 256, device=DEV, seed=11)
+    pol = BatchedPolicy(V, 5, F1, F2, device=DEV, seed=11)
     with torch.no_grad():                       # heads start at +-0.003: widen them so the outputs are not all ~0
         pol.Wh.mul_(60.0)
     obs = rng.uniform(0, 1.2, (E, V, 5)).astype(np.float32)
