@@ -167,6 +167,11 @@ def main() -> None:
                          "it is amortised rather than issued every step; at 32 its duty cycle stays near 20 %%.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lean", action="store_true", help="experiment: skip metrics and obs writes")
+    ap.add_argument("--steer", action="store_true",
+                    help="fused / bcd modes: the steering form of the gain+step kernel (RISVEC_STEP_STEER): h_r is not "
+                         "read, the cascade is the polynomial sum_m theta_m b_m z^m evaluated by Horner in float64 from "
+                         "the 16-byte steering base of each vehicle.  Only meaningful for the reference's own physics "
+                         "(h_r from compute_parms), not for arbitrary synthetic channel draws -- NOT the headline.")
     ap.add_argument("--mode", default="fused", choices=["fused", "cached", "bcd", "sarl"],
                     help="fused: gains+step each step (headline); cached: step only (reference cadence); "
                          "bcd: BCD sweep + gains + step each step (BASELINE config 5); "
@@ -265,7 +270,7 @@ def main() -> None:
         launch = lambda: env.sarl_step(action, phase, None, sp, obs=full)       # noqa: E731
     else:
         launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full, power_w=False,
-                               obs=full)
+                               obs=full, steer=args.steer and fused)
     episode_len = 100
 
     def one_step(i: int) -> None:
@@ -314,6 +319,8 @@ def main() -> None:
     if rank != 0:
         return
     per_env = algorithmic_bytes(V, M, args.mode)
+    if args.steer and fused:            # h_r (8VM) replaced by the float64 steering bases (16V)
+        per_env += 16 * V - 8 * V * M
     bytes_per_launch = per_env * E
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     kname = {"fused": "k_step_fused", "cached": "k_step<", "bcd": "k_bcd", "sarl": "SarlCore"}[args.mode]
@@ -344,10 +351,11 @@ def main() -> None:
                    "replay": ("marshal + HBM replay ring store every step (%d B per transition)"
                               % (4 * (10 * V + V * (V + 2) + V + 1 + V * V) + 1) if args.replay else "off"),
                    "policy": "BatchedPolicy 8x(5-512-256), every step" if args.policy else "synthetic outputs",
+                   "steering_form": bool(args.steer and fused),
                    "agent_steps_per_s": E * world * args.steps / dt * V},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"fused": "k_step_fused_pipe<8,64,2,MarlCore>" if (V, M) == (8, 64) else "k_step_fused*",
+                     "kernel": "k_step_steer" if (args.steer and fused) else {"fused": "k_step_fused_pipe<8,64,2,MarlCore>" if (V, M) == (8, 64) else "k_step_fused*",
                                 "cached": "k_step", "bcd": "k_bcd_lane + k_step_fused*",
                                 "sarl": "k_set_phase + k_step_fused_pipe<..,SarlCore>"}[args.mode],
                      "algorithmic_bytes_per_env_step": per_env, "bytes_per_launch": bytes_per_launch,

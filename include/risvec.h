@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 7
+#define RISVEC_ABI_VERSION 8
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -59,7 +59,12 @@ enum {
                                        marl_train_bcd.py:1601-1608 in-kernel             */
     RISVEC_STEP_OBS = 8,            /* write obs[E,V,5] (marl_train_bcd.py:819-827)        */
     RISVEC_STEP_REUSE_COLSUM = 16,  /* risvec_step_fused_bcd: c_col is current, skip its rebuild */
-    RISVEC_STEP_REUSE_SSUM = 32     /* risvec_step_fused_bcd: s_sum is current (see RISVEC_BCD_REUSE_SSUM) */
+    RISVEC_STEP_REUSE_SSUM = 32,    /* risvec_step_fused_bcd: s_sum is current (see RISVEC_BCD_REUSE_SSUM) */
+    RISVEC_STEP_STEER = 64          /* risvec_step_fused: h_r is the steering vector risvec_geometry wrote
+                                       (phases_R_i[v,m] = z_v^m, z_v = exp(-j pi angle_v), ENV:249-253): do not
+                                       read it; evaluate sum_m theta_m b_m z^m by Horner in float64 from
+                                       state.z_r (16 bytes per vehicle instead of 8M).  Only valid while h_r is
+                                       what the geometry kernel produced -- not for arbitrary channel draws. */
 };
 
 /* risvec_bcd flags */
@@ -153,6 +158,9 @@ typedef struct RisVecState {
     double *s_sum;          /* [E]     c128; S = sum_m theta_m c_m left by the last BCD sweep (may be NULL) */
     /* SARL variant only (Simulation-SARL/Environment.py:337-340); the MARL step never writes it */
     float *over_data;       /* [E,V]   (may be NULL for MARL-only use)                 */
+    /* steering base z[e,v] = exp(-j pi angle_R[e,v]) in float64 (h_r[e,v,m] = z^m); written by risvec_geometry
+       when non-NULL, read by risvec_step_fused with RISVEC_STEP_STEER */
+    double *z_r;            /* [E,V]   c128 (may be NULL)                                 */
 } RisVecState;
 
 /* Parameters of the single-agent (SARL) environment variant,

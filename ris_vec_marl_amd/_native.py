@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -22,6 +22,7 @@ DIR_U, DIR_D, DIR_L, DIR_R = range(4)
 CH_FREE, CH_3GPP_UMI, CH_3GPP_UMA, CH_OTHER = range(4)
 STEP_METRICS, STEP_POWER_W, STEP_POLICY_ACTION, STEP_OBS, STEP_REUSE_COLSUM = 1, 2, 4, 8, 16
 STEP_REUSE_SSUM = 32
+STEP_STEER = 64
 BCD_REUSE_COLSUM, BCD_REUSE_SSUM = 1, 2
 
 METRIC_NAMES = (
@@ -65,7 +66,7 @@ class RisVecState(C.Structure):
         ("theta", _FP), ("b", _FP), ("h_d", _FP), ("gain", _FP),
         ("data_buf", _FP), ("mec_q", _FP),
         ("rate", _FP), ("data_t", _FP), ("data_p", _FP), ("reward", _FP), ("over_power", _FP),
-        ("obs", _FP), ("metrics", _FP), ("power_w", _FP), ("c_col", _FP), ("s_sum", _FP), ("over_data", _FP),
+        ("obs", _FP), ("metrics", _FP), ("power_w", _FP), ("c_col", _FP), ("s_sum", _FP), ("over_data", _FP), ("z_r", _FP),
     ]
 
 

@@ -199,7 +199,7 @@ constexpr int kGeoChunk = 16;
 template <bool STAGED>
 __global__ void __launch_bounds__(kBlock)
 k_geometry(Dims d, const double* __restrict__ pos, float* __restrict__ dist_r,
-           float* __restrict__ ang_r, float* __restrict__ pl, float* __restrict__ h_r) {
+           float* __restrict__ ang_r, float* __restrict__ pl, float* __restrict__ h_r, double* __restrict__ z_r) {
     const int nchunk = (d.M + kGeoChunk - 1) / kGeoChunk;
     long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
     const bool in_range = idx < (long long)d.E * d.V * nchunk;
@@ -225,6 +225,7 @@ k_geometry(Dims d, const double* __restrict__ pos, float* __restrict__ dist_r,
     sincospi(ang, &ws, &wc);                       // w = exp(-j pi ang)    = (wc, -ws)
     double zr = zc, zi = -zs;
     const double wr = wc, wi = -ws;
+    if (z_r && m0 == 0 && in_range) reinterpret_cast<double2*>(z_r)[ev] = make_double2(wr, wi);   // h_r[e,v,m] = w^m
     float* out = h_r + (ev * d.M + m0) * 2;
     if constexpr (STAGED) {
         // M % 16 == 0: every lane owns one full 128-byte chunk and the block's 256 chunks are contiguous
@@ -375,10 +376,10 @@ hipError_t launch_geometry(const RisVecState& s, const RisVecParams&, hipStream_
     const long long n = (long long)s.n_envs * s.n_veh * ((s.n_ris + kGeoChunk - 1) / kGeoChunk);
     if (s.n_ris % kGeoChunk == 0)
         hipLaunchKernelGGL(k_geometry<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, dims_of(s), s.pos,
-                           s.dist_r, s.ang_r, s.pl, s.h_r);
+                           s.dist_r, s.ang_r, s.pl, s.h_r, s.z_r);
     else
         hipLaunchKernelGGL(k_geometry<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, dims_of(s), s.pos,
-                           s.dist_r, s.ang_r, s.pl, s.h_r);
+                           s.dist_r, s.ang_r, s.pl, s.h_r, s.z_r);
     return hipGetLastError();
 }
 

@@ -17,6 +17,8 @@
 //     reduced sums in its private LDS slice, then every lane picks up "its" (env,
 //     vehicle) sum and runs the step.  One HBM pass over h_r/theta, gains never
 //     round-trip through HBM before use.
+#include <type_traits>
+
 #include "risvec_step.hpp"
 
 namespace risvec {
@@ -110,6 +112,106 @@ k_step_fused(Dims d, RisVecParams P, StepArgs A) {
 // launchers
 // ---------------------------------------------------------------------------
 
+// "Steering" form of the fused kernel (RISVEC_STEP_STEER).  compute_parms makes every row of h_r a
+// geometric sequence, h_r[e,v,m] = z^m with z = exp(-j pi angle_v) (ENV:249-253), so the cascade
+// sum_m theta_m b_m h_r[e,v,m] is the polynomial sum_m w_m z^m, w = theta * b.  Instead of streaming the
+// 8M-byte row from HBM, a lane reads its 16-byte z (float64) and evaluates the polynomial by Horner's
+// rule in float64 -- four interleaved chains in z^4, so the dependent chain is M/4 long -- against the
+// env's w row staged once per wavefront in LDS.  Accumulated error ~M * 2^-53: better than the float32
+// sum over the stored float32 row.  Per env-step the kernel moves 16V + 8M + 64V + 68 bytes instead of
+// 8VM + 8M + 64V + 68 (1 220 vs 5 188 at V = 8, M = 64).
+// WIDE: the staged w row is widened to float64 once (saves two conversions per Horner step) when 4
+// wavefronts' worth of it still leaves room for several blocks per CU; long rows stay float32 in LDS.
+template <int VP, bool WIDE>
+__global__ void __launch_bounds__(kBlock)
+k_step_steer(Dims d, RisVecParams P, StepArgs A, const double* __restrict__ z_r) {
+    constexpr int EPW = kWave / VP;                        // envs per wave
+    using W2 = typename std::conditional<WIDE, double2, float2>::type;
+    extern __shared__ double2 s_wrow_raw[];                // [waves][EPW][M + 1]   w = theta * b (padded rows)
+    W2* s_wrow = reinterpret_cast<W2*>(s_wrow_raw);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int V = d.V, M = d.M, MS = M + 1;
+    const int e0 = (blockIdx.x * (blockDim.x / kWave) + wave) * EPW;
+    W2* sw = s_wrow + (long long)wave * EPW * MS;
+    const int e_mine = e0 + lane / VP, v_mine = lane % VP;
+    const bool active = e_mine < d.E && v_mine < V;
+    const StepIn in = load_step_in(d, A, e_mine, v_mine, active);
+    double2 z = make_double2(1.0, 0.0);
+    if (active) z = reinterpret_cast<const double2*>(z_r)[(long long)e_mine * V + v_mine];
+    for (int idx = lane; idx < EPW * M; idx += kWave) {   // coalesced theta rows of the wave's envs
+        const int i = idx / M, m = idx - i * M;
+        const int e = e0 + i;
+        float2 w = make_float2(0.f, 0.f);
+        if (e < d.E) {
+            const float2 t = *reinterpret_cast<const float2*>(A.theta + ((long long)e * M + m) * 2);
+            w = cmul(t, *reinterpret_cast<const float2*>(A.b + m * 2));
+        }
+        if constexpr (WIDE) sw[i * MS + m] = make_double2((double)w.x, (double)w.y);
+        else sw[i * MS + m] = w;
+    }
+    __syncthreads();
+    // z^2, z^4 and four Horner chains over m = 4k + r, highest power first
+    const double z2r = z.x * z.x - z.y * z.y, z2i = 2.0 * z.x * z.y;
+    const double z4r = z2r * z2r - z2i * z2i, z4i = 2.0 * z2r * z2i;
+    const W2* wr = sw + (lane / VP) * MS;
+    double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};
+    const int M4 = (M + 3) / 4;
+    for (int k = M4 - 1; k >= 0; --k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * k + r;
+            double wx = 0.0, wy = 0.0;
+            if (m < M) { const W2 w = wr[m]; wx = (double)w.x; wy = (double)w.y; }
+            const double nr = ar[r] * z4r - ai[r] * z4i + wx;
+            const double ni = ar[r] * z4i + ai[r] * z4r + wy;
+            ar[r] = nr; ai[r] = ni;
+        }
+    }
+    // sum_r z^r acc_r = acc0 + z (acc1 + z (acc2 + z acc3))
+    double sr = ar[3], si = ai[3];
+#pragma unroll
+    for (int r = 2; r >= 0; --r) {
+        const double nr = sr * z.x - si * z.y + ar[r], ni = sr * z.y + si * z.x + ai[r];
+        sr = nr; si = ni;
+    }
+    float g = 0.f;
+    if (active) {
+        const long long idx = (long long)e_mine * V + v_mine;
+        g = gain_from_img(make_float2((float)sr, (float)si), in.pl, A.h_d, idx);
+        A.gain[idx] = g;
+    }
+    step_core<VP>(d, P, A, e_mine, v_mine, active, g, in);
+}
+
+template <int VP>
+static hipError_t launch_steer_vp(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
+    constexpr int EPW = kWave / VP;
+    const size_t row = (size_t)EPW * (s.n_ris + 1);
+    const bool wide = row * sizeof(double2) * (kBlock / kWave) <= 40 * 1024;     // >= 4 blocks per CU either way
+    const size_t per_wave = row * (wide ? sizeof(double2) : sizeof(float2));
+    int waves = (int)((64 * 1024) / per_wave);             // as many wavefronts per block as 64 KB of LDS hold
+    if (waves < 1) return hipErrorNotSupported;            // theta rows do not fit: use the streaming kernel
+    if (waves > kBlock / kWave) waves = kBlock / kWave;
+    const long long n_waves = ((long long)s.n_envs + EPW - 1) / EPW;
+    const dim3 grid((unsigned)((n_waves + waves - 1) / waves)), block(waves * kWave);
+    if (wide) hipLaunchKernelGGL((k_step_steer<VP, true>), grid, block, per_wave * waves, st, dims_of(s), p, a, s.z_r);
+    else hipLaunchKernelGGL((k_step_steer<VP, false>), grid, block, per_wave * waves, st, dims_of(s), p, a, s.z_r);
+    return hipGetLastError();
+}
+
+hipError_t launch_step_steer(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
+    switch (pow2_ceil(s.n_veh)) {
+        case 1: return launch_steer_vp<1>(s, p, a, st);
+        case 2: return launch_steer_vp<2>(s, p, a, st);
+        case 4: return launch_steer_vp<4>(s, p, a, st);
+        case 8: return launch_steer_vp<8>(s, p, a, st);
+        case 16: return launch_steer_vp<16>(s, p, a, st);
+        case 32: return launch_steer_vp<32>(s, p, a, st);
+        case 64: return launch_steer_vp<64>(s, p, a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <int G>
 static hipError_t launch_gain_g(const RisVecState& s, hipStream_t st) {
     const long long units = (long long)s.n_envs * s.n_veh;
@@ -166,7 +268,12 @@ static hipError_t launch_step_vp(const RisVecState& s, const RisVecParams& p, co
 hipError_t launch_step(const RisVecState& s, const RisVecParams& p, const float* action,
                        const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals,
                        uint64_t seed, uint32_t counter, uint32_t flags, bool fused, hipStream_t st) {
-    const StepArgs a = make_step_args(s, action, partner, n_groups, arrivals, seed, counter, flags);
+    const StepArgs a = make_step_args(s, action, partner, n_groups, arrivals, seed, counter,
+                                      flags & ~(uint32_t)RISVEC_STEP_STEER);
+    if (fused && (flags & RISVEC_STEP_STEER)) {
+        const hipError_t err = launch_step_steer(s, p, a, st);
+        if (err != hipErrorNotSupported) return err;       // theta rows too long for LDS: stream h_r as usual
+    }
     if (fused) {
         const hipError_t err = launch_step_fused_pipe(s, p, a, st);
         if (err != hipErrorNotSupported) return err;

@@ -73,8 +73,12 @@ int check_step(const char* fn, const RisVecState* s, const float* action, const 
     if (flags & RISVEC_STEP_OBS) REQ_PTR(s->obs, "state.obs");
     if (flags & RISVEC_STEP_POWER_W) REQ_PTR(s->power_w, "state.power_w");
     if (flags & ~(uint32_t)(RISVEC_STEP_METRICS | RISVEC_STEP_POWER_W | RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS |
-                            RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM))
+                            RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_STEER))
         return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
+    if (flags & RISVEC_STEP_STEER) {
+        if (!fused) return fail(RISVEC_ERR_ARG, "%s: RISVEC_STEP_STEER needs the fused entry points", fn);
+        REQ_PTR(s->z_r, "state.z_r");
+    }
     if (fused) {
         REQ_PTR(s->h_r, "state.h_r"); REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->b, "state.b");
         REQ_PTR(s->pl, "state.pl"); OPT_PTR(s->h_d, "state.h_d");
@@ -158,6 +162,7 @@ int risvec_geometry(const RisVecState* s, const RisVecParams* p, risvec_stream_t
     if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     if (int rc = check_common(fn, s, p)) return rc;
     REQ_PTR(s->pos, "state.pos"); REQ_PTR(s->dist_r, "state.dist_r"); REQ_PTR(s->ang_r, "state.ang_r");
+    OPT_PTR(s->z_r, "state.z_r");
     REQ_PTR(s->pl, "state.pl"); REQ_PTR(s->h_r, "state.h_r");
     OPT_PTR(s->c_col, "state.c_col");
     if (int rc = finish(fn, risvec::launch_geometry(*s, *p, (hipStream_t)stream))) return rc;

@@ -918,3 +918,45 @@ def test_determinism_and_side_stream():
     c = run(torch.cuda.Stream())
     for x, y, z in zip(a, b, c):
         assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
+@pytest.mark.parametrize("shape", [(8, 64), (16, 256), (4, 16), (8, 36), (5, 40)])
+def test_steering_form_of_the_fused_step(shape):
+    """RISVEC_STEP_STEER: the cascade as the polynomial sum_m theta_m b_m z^m (Horner in float64 from the
+    steering base compute_parms stores) instead of a pass over h_r.  Gains against the float64 oracle at 1e-5
+    (they are in fact closer than the streaming kernel's), against the streaming fused kernel at 3e-6, and the
+    step outputs of the two forms agree wherever no threshold sits inside that difference."""
+    V, M = shape
+    E = 512
+    rng = np.random.default_rng(V * 1000 + M)
+    envs = []
+    for _ in range(2):
+        env = make_vec(E, V, M, yaml=True)
+        env.make_new_game(); env.renew_positions(); env.renew_positions(); env.compute_parms(); env.Random_phase()
+        envs.append(env)
+    action = torch.from_numpy(rng.uniform(0, 1, (E, 2, V)).astype(np.float32)).to("cuda:0")
+    partner = torch.full((E, V), -1, dtype=torch.int32, device="cuda:0")
+    ng = torch.full((E,), V, dtype=torch.int32, device="cuda:0")
+    arr = torch.from_numpy(rng.poisson(1.0, (E, V)).astype(np.int32)).to("cuda:0")
+    envs[0].step(action, partner, ng, arr, fused=True)
+    envs[1].step(action, partner, ng, arr, fused=True, steer=True)
+    g0, g1 = envs[0].tensors["gain"].cpu().numpy().astype(np.float64), envs[1].tensors["gain"].cpu().numpy().astype(np.float64)
+    # float32 sums of M terms carry an error relative to the COHERENT scale pl * M^2, not to a gain that
+    # destructive interference made small: 1e-5 relative + 1e-7 of that scale
+    scale = envs[1].tensors["pl"].cpu().numpy().astype(np.float64) * M * M
+    assert np.all(np.abs(g1 - g0) <= 1e-5 * g0 + 1e-7 * scale)
+    t = envs[1].tensors
+    theta = t["theta"].cpu().numpy().astype(np.float64)
+    h_r = t["h_r"].cpu().numpy().astype(np.float64)
+    go = orc.gain_free(theta[..., 0] + 1j * theta[..., 1], h_r[..., 0] + 1j * h_r[..., 1], orc.phase_R(M).astype(np.complex64),
+                       t["dist_r"].cpu().numpy().astype(np.float64))
+    assert np.all(np.abs(g1 - go) <= 1e-5 * go + 1e-7 * scale)
+    assert np.abs(g1 - go).max() <= np.abs(g0 - go).max() * 1.5 + 1e-30      # the float64 Horner is not the less exact form
+    for k in ("reward", "data_buf", "data_t", "data_p"):
+        a, b = envs[0].tensors[k].cpu().numpy(), envs[1].tensors[k].cpu().numpy()
+        bad = np.abs(a - b) > 1e-5 * (1 + np.abs(a))
+        assert bad.mean() < 2e-3, (k, bad.mean())
+    # h_r written by hand has no steering base: the flag is refused
+    envs[1].rebuild_colsum()
+    with pytest.raises(ValueError):
+        envs[1].step(action, partner, ng, arr, fused=True, steer=True)
