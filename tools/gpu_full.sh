@@ -32,6 +32,9 @@ b replay --replay
 b cached_replay --mode cached --replay
 b sarl --mode sarl
 b policy --policy --steps 300 --warmup 30
+b steer --steer
+b c5_steer --veh 16 --ris 256 --mode bcd --steps 300 --warmup 30 --steer
+b replay_steer --replay --steer
 echo "== streaming yardstick" | tee -a $OUT/round_$TAG.log
 timeout -k 10 300 python tools/membench.py > $OUT/membench_$TAG.jsonl 2>/dev/null; cat $OUT/membench_$TAG.jsonl
 echo "== 2-rank rehearsal on one GPU (gloo for the collective; RCCL needs one GPU per rank)" | tee -a $OUT/round_$TAG.log

@@ -42,6 +42,7 @@ for _ in range(reps):
     env.data_rate(pw, partner, ng)
     env.step(action, partner, ng, None, fused=False, power_w=False)
     env.step(action, partner, ng, None, fused=True, power_w=False)
+    env.step(action, partner, ng, None, fused=True, power_w=False, steer=True)      # k_step_steer
     env.sarl_step(action, phase)
     env.channel_model = "3gpp_umi"
     env.update_channel_gains()
@@ -65,6 +66,7 @@ B = dict(
     k_colsum=E * (8 * V * M + 16 * M), k_random_phase=E * 8 * M, k_set_phase=E * 12 * M,
     k_bcd_sweep=E * (2 * 16 * M + 2 * 8 * M + 8 * M), k_gain=E * (8 * V * M + 8 * M + 8 * V),
     k_data_rate=E * 16 * V + 4 * E, k_step=E * (60 * V + 68), k_step_fused=E * (8 * V * M + 8 * M + 64 * V + 68),
+    k_step_steer=E * (16 * V + 8 * M + 64 * V + 68),
     k_sarl_step=E * (8 * V * M + 8 * M + 48 * V + 4), k_gain_3gpp=E * V * 20,
     # f2 / f3 (float words read + written; the NOMA kernels are latency-bound, bytes listed for completeness)
     k_replay_store=E * (2 * 4 * (2 * 5 * V + V * (V + 2) + V + 1) + 5 * V * V + 1),
