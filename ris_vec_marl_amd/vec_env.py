@@ -468,7 +468,7 @@ class VecEnviron(ParamAttrs):
         t = self.tensors
         sd: Dict[str, object] = {k: t[k].detach().cpu().clone() for k in self._STATE_KEYS}
         sd["counters"] = dict(epoch=self._epoch, moves=self._moves, steps=self._steps, chan=self._chan,
-                              seed=self.seed, env_offset=self.env_offset)
+                              seed=self.seed, env_offset=self.env_offset, steer_valid=self._steer_valid)
         return sd
 
     def load_state_dict(self, sd: Dict[str, object]) -> None:
@@ -479,6 +479,7 @@ class VecEnviron(ParamAttrs):
         self._ssum_sweeps = 0
         c = sd["counters"]
         self._epoch, self._moves, self._steps, self._chan = c["epoch"], c["moves"], c["steps"], c["chan"]
+        self._steer_valid = bool(c.get("steer_valid", False))      # z_r travels with h_r
 
 
 # reference attribute name -> tensor key
