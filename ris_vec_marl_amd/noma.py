@@ -230,8 +230,8 @@ class NomaGrouper:
               gdb15: Optional[torch.Tensor] = None, u_unstick: Optional[torch.Tensor] = None
               ) -> Tuple[torch.Tensor, torch.Tensor]:
         """TRAIN:1401-1562 for every env -> (partner [E,N] int32, n_groups [E] int32), the batched
-        `noma_groups` `VecEnviron.step` takes (views of the grouper's state, valid until the next call).  `p_off01` [E,N] is the offload power in [0,1] the
-        policy chose (TRAIN:1391-1396).  `prev_global` defaults to the global reward the env's last
+        `noma_groups` `VecEnviron.step` takes (views of the grouper's state, valid until the next call).
+        `p_off01` [E,N] is the offload power in [0,1] the policy chose (TRAIN:1391-1396).  `prev_global` defaults to the global reward the env's last
         `step` left in `metrics[:,0]` (none before the first step of the episode).  `gdb12` / `gdb15`
         inject a host's float64 dB gains (parity interface); `u_unstick` injects the TRAIN:1539 draw."""
         self._ensure_device()
