@@ -87,10 +87,16 @@ __device__ __forceinline__ float replay_hist(float h, int pending, float decay, 
 // (`flags_out` = its updated flag bits, handed to the solving wavefront through a shuffle).
 __device__ __forceinline__ bool noma_pre_env(const NomaArgs& A, int env, int& flags_out) {
     const RisVecNomaParams& P = A.P;
+    // every load of the frozen path up front: one memory round trip instead of five dependent ones (a frozen
+    // step is nothing but this function, so its latency IS the step's cost)
     int flags = A.ns.flags[env];
     double last = A.ns.last_global[env], best = A.ns.best_global[env];
+    const float prev = A.prev_global ? A.prev_global[(long long)env * A.prev_stride] : 0.0f;
+    const int pend = A.ns.pending[env];
+    const int n_groups = A.ns.n_groups[env];
+    const float u_in = A.u_unstick ? A.u_unstick[env] : 0.0f;
     if (A.prev_global) {                               // TRAIN:1618-1623, for the step that just ran
-        const double g = (double)A.prev_global[(long long)env * A.prev_stride];
+        const double g = (double)prev;
         if (!(flags & RISVEC_NOMA_HAS_LAST)) best = g;
         else if (g > best) best = g;
         last = g;
@@ -110,7 +116,7 @@ __device__ __forceinline__ bool noma_pre_env(const NomaArgs& A, int env, int& fl
         }
         if (!need_repair && P.freeze_unstick_prob > 0.0) {
             const double u = A.u_unstick
-                ? (double)A.u_unstick[env]
+                ? (double)u_in
                 : (double)u01(philox4x32_10((uint32_t)(A.ns.env_offset + env), 0u, A.counter, kSiteUnstick, A.seed).x);
             if (u < P.freeze_unstick_prob) need_repair = true;
         }
@@ -118,16 +124,15 @@ __device__ __forceinline__ bool noma_pre_env(const NomaArgs& A, int env, int& fl
     A.ns.flags[env] = (uint8_t)flags;
     flags_out = flags;
     if (frozen && !need_repair) {                      // reuse episode_groups (TRAIN:1542-1547): defer the bookkeeping
-        A.ns.pending[env] += 1;
+        A.ns.pending[env] = pend + 1;
         if (A.info_out) {
             int* o = A.info_out + (long long)env * 4;
-            o[0] = 0; o[1] = 0; o[2] = A.ns.n_veh - A.ns.n_groups[env]; o[3] = 0;
+            o[0] = 0; o[1] = 0; o[2] = A.ns.n_veh - n_groups; o[3] = 0;
         }
         return false;
     }
     return true;
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // flush: materialise the deferred frozen steps (one lane per matrix entry)
@@ -271,6 +276,9 @@ __device__ __forceinline__ double best_at(const MatchTab& M, const double* w, co
 // envs each), so a frozen step launches no more blocks than that.
 template <int NMAX> struct EnvsPerWave { static constexpr int value = NMAX <= 8 ? 8 : 32; };
 
+// (One long function on purpose: split into inlined helpers over a shared-memory struct the same code ran the
+// 16-user kernel's frozen path 4x slower and its solves 5 % slower, A/B on one box -- the compiler's schedule
+// of this kernel is that sensitive to its shape.)
 template <int NMAX>
 __global__ void __launch_bounds__(kWave, NMAX <= 8 ? 5 : 1)
 k_noma_group(NomaArgs A) {
@@ -301,20 +309,24 @@ k_noma_group(NomaArgs A) {
     if (todo == 0) continue;                           // the common case: all 8 envs frozen
     if (!tables_ready) {
     tables_ready = true;
+    // Only the (rare) wavefronts that solve anything need the tables below; the opaque move keeps the compiler
+    // from hoisting their arithmetic into a prologue every frozen-step wavefront would then pay for.
+    int tl = lane;
+    asm volatile("" : "+v"(tl));
     // binomials C(c, i) and their prefix sums over i (Pascal rows; one row per lane)
-    if (lane < 16) {
+    if (tl < 16) {
         int c = 1;                                     // C(lane, 0)
         int off = 0;
         for (int i = 0; i <= kBinW; ++i) {
-            if (i < kBinW) s_binom[lane * kBinW + i] = c;
-            s_sizeoff[lane * (kBinW + 1) + i] = off;
+            if (i < kBinW) s_binom[tl * kBinW + i] = c;
+            s_sizeoff[tl * (kBinW + 1) + i] = off;
             off += c;
-            c = i < lane ? c * (lane - i) / (i + 1) : 0;   // C(lane, i+1)
+            c = i < tl ? c * (tl - i) / (i + 1) : 0;       // C(lane, i+1)
         }
     }
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
-        const int idx = lane + t * kWave;
+        const int idx = tl + t * kWave;
         ein[t] = idx < NN;
         ei[t] = ein[t] ? idx / N : 0;
         ej[t] = ein[t] ? idx % N : 0;
