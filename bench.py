@@ -186,6 +186,9 @@ def main() -> None:
                     help="with --replay: the actions come from the batched SAC policy (BatchedPolicy: 8 x (5-512-256) "
                          "networks over all envs, rocBLAS GEMMs + the fused sampling/marshalling kernel) instead of "
                          "pre-drawn synthetic policy outputs")
+    ap.add_argument("--meter", action="store_true",
+                    help="f4: add every step's metrics / rewards / powers to the per-env episode accumulators "
+                         "(EpisodeMeter) and reduce the episode scalars over the envs every 100 steps")
     args = ap.parse_args()
     if args.policy:
         args.replay = True
@@ -269,9 +272,16 @@ def main() -> None:
         sp = SarlParams()
         launch = lambda: env.sarl_step(action, phase, None, sp, obs=full)       # noqa: E731
     else:
-        launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full, power_w=False,
-                               obs=full, steer=args.steer and fused)
+        launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full,
+                               power_w=args.meter, obs=full, steer=args.steer and fused)
     episode_len = 100
+    meter = meter_add = None
+    if args.meter:
+        if args.mode == "sarl" or not full:
+            raise SystemExit("--meter needs the MARL step with metrics written")
+        from ris_vec_marl_amd import EpisodeMeter
+        meter = EpisodeMeter(env)
+        meter_add = meter.bind(env)
 
     def one_step(i: int) -> None:
         if grouper is not None:
@@ -285,6 +295,12 @@ def main() -> None:
         launch()
         if store is not None:
             store(done=(i % episode_len) == episode_len - 1, use_mask=(i % episode_len) == 0)
+        if meter is not None:
+            if i % episode_len == 0:
+                meter.begin_episode()
+            meter_add()
+            if i % episode_len == episode_len - 1:
+                meter.summarize()
         if gather is not None and i % args.gather_every == 0:
             gather.start(env.tensors["obs"])
 
@@ -352,6 +368,8 @@ def main() -> None:
                               % (4 * (10 * V + V * (V + 2) + V + 1 + V * V) + 1) if args.replay else "off"),
                    "policy": "BatchedPolicy 8x(5-512-256), every step" if args.policy else "synthetic outputs",
                    "steering_form": bool(args.steer and fused),
+                   "episode_meter": ("float64 episode sums of E x (17+V) columns every step, summary every 100 steps"
+                                     if args.meter else "off"),
                    "agent_steps_per_s": E * world * args.steps / dt * V},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 8
+#define RISVEC_ABI_VERSION 9
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -458,6 +458,61 @@ int risvec_policy_layer1(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t
 int risvec_policy_heads(int32_t n_envs, int32_t n_veh, int32_t f2, int32_t n_heads, const float *g, const float *b2,
                         const float *ln_w, const float *ln_b, const float *Wh, const float *bh, float *heads,
                         risvec_stream_t stream);
+
+/* ---- f4: the per-episode metrics sink --------------------------------------------------
+ * The driver sums the `last_*` scalars, the clipped per-user rewards and the equivalent powers step by
+ * step in Python floats and turns them into per-episode scalars for TensorBoard (marl_train_bcd.py,
+ * TRAIN below: 1611-1662 accumulate, 1714 clip, 1717-1753 power, 1769 per-user sums, 1824 and 1838-1865
+ * means, 1939-1941 min / var / Jain, 1927-2048 the tags).  Here every env keeps its own float64
+ * accumulators on the device and the episode summary is reduced over the envs in two launches.
+ *
+ * acc [RISVEC_EP_FIXED + V, E] doubles (column-major: one row per quantity, envs contiguous), rows:
+ *   0..13   sum over the episode's steps of metrics[slot]            (TRAIN:1626-1662)
+ *   14      sum of sum_v power_w[0,v]  (offload, equivalent watts)    (TRAIN:1752)
+ *   15      sum of sum_v power_w[1,v]  (local)                        (TRAIN:1753)
+ *   16      max over the steps of the global reward (`ep_env_best`)   (TRAIN:1613-1622)
+ *   17+v    sum of clip(reward_v, -user_clip, +user_clip)             (TRAIN:1714, 1769)            */
+#define RISVEC_EP_FIXED 17
+#define RISVEC_EP_COLS 21
+enum {
+    RISVEC_EP_GLOBAL_AVG = 0,      /* reward/global_avg            mean of the global reward       (1838) */
+    RISVEC_EP_OFF_KBIT = 1,        /* traffic/offload_kbit_ep      SUM over the episode           (2047) */
+    RISVEC_EP_LOCAL_KBIT = 2,      /* traffic/local_kbit_ep        SUM                            (2048) */
+    RISVEC_EP_MEC_CYCLES = 3,      /* queue/mec_cycles             value after the LAST step      (1974) */
+    RISVEC_EP_BACKLOG = 4,         /* queue/backlog_kbit_ep_mean                                  (1862) */
+    RISVEC_EP_DELAY_LOCAL = 5,     /* delay/local_ep_mean                                         (1858) */
+    RISVEC_EP_DELAY_EDGE_Q = 6,    /* delay/edge_queue_ep_mean                                    (1859) */
+    RISVEC_EP_DELAY_EDGE_C = 7,    /* delay/edge_compute_ep_mean                                  (1860) */
+    RISVEC_EP_DELAY_TX = 8,        /* delay/tx_ep_mean                                            (1861) */
+    RISVEC_EP_MEC_UTIL = 9,        /* queue/mec_util_ep_mean                                      (1863) */
+    RISVEC_EP_LOCAL_UTIL = 10,     /* cpu/local_util_ep_mean                                      (1864) */
+    RISVEC_EP_QOS_VIOL = 11,       /* qos/violation_rate_ep_mean                                  (1865) */
+    RISVEC_EP_DELAY = 12,          /* delay/episode_mean  (abs/delay_ms = 1000 x this)            (1850) */
+    RISVEC_EP_ENERGY = 13,         /* energy/episode_mean (abs/energy_J)                          (1851) */
+    RISVEC_EP_POWER_OFFLOAD = 14,  /* power/offload_avg                                           (1843) */
+    RISVEC_EP_POWER_LOCAL = 15,    /* power/local_avg                                             (1842) */
+    RISVEC_EP_POWER_TOTAL = 16,    /* power/total_avg                                             (1841) */
+    RISVEC_EP_MIN_USER = 17,       /* min over users of the per-user episode mean                 (1939) */
+    RISVEC_EP_VAR_USER = 18,       /* population variance of the same                             (1940) */
+    RISVEC_EP_JAIN = 19,           /* (sum x)^2 / (V sum x^2 + 1e-12)                         (112-119) */
+    RISVEC_EP_BEST_GLOBAL = 20     /* best global reward of the episode                           (1613) */
+};
+
+/* Zero acc (column 16 to -inf).  Call where the driver resets its ep_* sums (TRAIN:1278-1300). */
+int risvec_episode_clear(int32_t n_envs, int32_t n_veh, double *acc, risvec_stream_t stream);
+
+/* One step's contribution: metrics [E,16] and reward [E,V] as the step kernel wrote them, power_w
+ * [E,2,V] or NULL (then columns 14/15 stay untouched, as when the env has no last_power_W). */
+int risvec_episode_accumulate(int32_t n_envs, int32_t n_veh, const float *metrics, const float *reward,
+                              const float *power_w, float user_clip, double *acc, risvec_stream_t stream);
+
+/* Episode end.  per_env [E, RISVEC_EP_COLS] (optional) receives every env's episode scalars; summary
+ * [3, RISVEC_EP_COLS] their mean / min / max over the envs, reduced in a fixed order (deterministic);
+ * partial is scratch of risvec_episode_partial_rows(n_envs) x 3 x RISVEC_EP_COLS doubles.  n_steps
+ * >= 1; metrics supplies column 3 (the queue after the last step). */
+int32_t risvec_episode_partial_rows(int32_t n_envs);
+int risvec_episode_summary(int32_t n_envs, int32_t n_veh, int32_t n_steps, const double *acc, const float *metrics,
+                           double *per_env, double *partial, double *summary, risvec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -13,9 +13,10 @@ from .sarl import SarlEnviron, SarlParams, sarl_action_map, sarl_observe
 from .noma import NomaConfig, NomaGrouper, anneal_topk
 from .replay import VecReplayBuffer, marshal_actions
 from .policy import BatchedPolicy
+from .metrics import EpisodeMeter, ScalarSink
 from . import dist
 
 __all__ = ["EnvParams", "apply_yaml_config", "load_yaml", "reference_lanes", "poisson_cdf_table",
            "VecEnviron", "Environ", "Vehicle", "encode_noma_groups", "SarlEnviron", "SarlParams", "sarl_action_map",
            "sarl_observe", "NomaConfig", "NomaGrouper", "anneal_topk", "VecReplayBuffer",
-           "marshal_actions", "BatchedPolicy", "dist"]
+           "marshal_actions", "BatchedPolicy", "EpisodeMeter", "ScalarSink", "dist"]

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -52,6 +52,9 @@ class RisVecParams(C.Structure):
         ("lanes_up", _LANES), ("lanes_down", _LANES), ("lanes_left", _LANES), ("lanes_right", _LANES),
     ]
 
+
+EP_FIXED = 17     # RISVEC_EP_FIXED: accumulator columns besides the V per-user sums
+EP_COLS = 21      # RISVEC_EP_COLS
 
 _FP = C.c_void_p
 
@@ -156,6 +159,10 @@ _PROTOS = {
     "risvec_policy_heads": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "risvec_policy_sample": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _FP, _FP, _FP, _FP, _FP, _FP, C.c_uint64, C.c_uint32,
                                        C.c_float, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "risvec_episode_clear": (C.c_int, [C.c_int32, C.c_int32, _FP, _FP]),
+    "risvec_episode_accumulate": (C.c_int, [C.c_int32, C.c_int32, _FP, _FP, _FP, C.c_float, _FP, _FP]),
+    "risvec_episode_partial_rows": (C.c_int32, [C.c_int32]),
+    "risvec_episode_summary": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP]),
 }
 
 EXPORTS = tuple(_PROTOS)   # every symbol include/risvec.h declares

@@ -512,4 +512,43 @@ int risvec_policy_heads(int32_t n_envs, int32_t n_veh, int32_t f2, int32_t n_hea
                                                   (hipStream_t)stream));
 }
 
+static int episode_dims(const char* fn, int32_t n_envs, int32_t n_veh) {
+    if (n_envs < 1) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d must be >= 1", fn, n_envs);
+    if (n_veh < 1 || n_veh > RISVEC_MAX_VEH)
+        return fail(RISVEC_ERR_SHAPE, "%s: n_veh=%d outside [1,%d]", fn, n_veh, RISVEC_MAX_VEH);
+    if ((long long)n_envs * (RISVEC_EP_FIXED + n_veh) >= (1LL << 31))
+        return fail(RISVEC_ERR_SHAPE, "%s: n_envs*(%d+n_veh) must stay below 2^31", fn, RISVEC_EP_FIXED);
+    return RISVEC_OK;
+}
+
+int risvec_episode_clear(int32_t n_envs, int32_t n_veh, double* acc, risvec_stream_t stream) {
+    const char* fn = "risvec_episode_clear";
+    if (int rc = episode_dims(fn, n_envs, n_veh)) return rc;
+    REQ_PTR(acc, "acc");
+    return finish(fn, risvec::launch_episode_clear(n_envs, n_veh, acc, (hipStream_t)stream));
+}
+
+int risvec_episode_accumulate(int32_t n_envs, int32_t n_veh, const float* metrics, const float* reward,
+                              const float* power_w, float user_clip, double* acc, risvec_stream_t stream) {
+    const char* fn = "risvec_episode_accumulate";
+    if (int rc = episode_dims(fn, n_envs, n_veh)) return rc;
+    REQ_PTR(metrics, "metrics"); REQ_PTR(reward, "reward"); OPT_PTR(power_w, "power_w"); REQ_PTR(acc, "acc");
+    if (!(user_clip >= 0.0f)) return fail(RISVEC_ERR_ARG, "%s: user_clip=%g must be >= 0", fn, (double)user_clip);
+    return finish(fn, risvec::launch_episode_accumulate(n_envs, n_veh, metrics, reward, power_w, user_clip, acc,
+                                                        (hipStream_t)stream));
+}
+
+int32_t risvec_episode_partial_rows(int32_t n_envs) { return n_envs < 1 ? 0 : risvec::episode_partial_rows(n_envs); }
+
+int risvec_episode_summary(int32_t n_envs, int32_t n_veh, int32_t n_steps, const double* acc, const float* metrics,
+                           double* per_env, double* partial, double* summary, risvec_stream_t stream) {
+    const char* fn = "risvec_episode_summary";
+    if (int rc = episode_dims(fn, n_envs, n_veh)) return rc;
+    if (n_steps < 1) return fail(RISVEC_ERR_ARG, "%s: n_steps=%d must be >= 1 (no step was accumulated)", fn, n_steps);
+    REQ_PTR(acc, "acc"); REQ_PTR(metrics, "metrics"); OPT_PTR(per_env, "per_env"); REQ_PTR(partial, "partial");
+    REQ_PTR(summary, "summary");
+    return finish(fn, risvec::launch_episode_summary(n_envs, n_veh, n_steps, acc, metrics, per_env, partial, summary,
+                                                     (hipStream_t)stream));
+}
+
 }  // extern "C"

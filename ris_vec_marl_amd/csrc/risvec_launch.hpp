@@ -71,6 +71,13 @@ hipError_t launch_policy_layer1(int E, int V, int IN, int F, const float* obs, c
 hipError_t launch_policy_heads(int E, int V, int F, int H, const float* g, const float* b2, const float* lw,
                                const float* lb, const float* Wh, const float* bh, float* heads, hipStream_t st);
 
+int episode_partial_rows(int E);
+hipError_t launch_episode_clear(int E, int V, double* acc, hipStream_t st);
+hipError_t launch_episode_accumulate(int E, int V, const float* metrics, const float* reward, const float* power_w,
+                                     float user_clip, double* acc, hipStream_t st);
+hipError_t launch_episode_summary(int E, int V, int n_steps, const double* acc, const float* metrics, double* per_env,
+                                  double* partial, double* summary, hipStream_t st);
+
 inline Dims dims_of(const RisVecState& s) {
     return Dims{s.n_envs, s.n_veh, s.n_ris, s.control_bit, (long long)s.env_offset};
 }

@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ris_vec_marl_amd import (VecEnviron, reference_lanes, apply_yaml_config, NomaGrouper, VecReplayBuffer,  # noqa: E402
-                              marshal_actions, BatchedPolicy)
+                              marshal_actions, BatchedPolicy, EpisodeMeter)
 
 E, V, M, reps = (int(x) for x in (sys.argv[1:5] + ["32768", "8", "64", "20"][len(sys.argv) - 1:]))
 L = reference_lanes()
@@ -31,6 +31,7 @@ replay = VecReplayBuffer(3 * E, 5, V + 2, V, device="cuda:0")
 power_raw = torch.from_numpy(rng.uniform(-1, 1, (E, V, 2)).astype(np.float32)).cuda()
 probs = torch.from_numpy(rng.dirichlet(np.ones(V), (E, V)).astype(np.float32)).cuda()
 policy = BatchedPolicy(V, 5, 512, 256, device="cuda:0")
+meter = EpisodeMeter(env)
 for _ in range(reps):
     env.make_new_game()
     env.renew_positions()
@@ -60,6 +61,9 @@ for _ in range(reps):
     replay.store_batch(obs, a_store, env.tensors["metrics"], env.tensors["reward"], obs, False, mask)   # k_replay_store
     replay.sample_buffer(4096)                                         # k_replay_sample
     policy.choose_action(obs, mask, cpu_share_floor=0.1)               # k_policy_layer1 + GEMM + k_policy_heads + k_policy_sample
+    meter.begin_episode()                                              # k_episode_clear
+    meter.accumulate(env)                                              # k_episode_accumulate
+    meter.summarize()                                                  # k_episode_summary + k_episode_fold
 torch.cuda.synchronize()
 B = dict(
     k_reset=E * V * (16 + 4 + 4 + 4), k_mobility=E * V * (16 + 4 + 4 + 16 + 4), k_geometry=E * V * (16 + 12 + 8 * M),
@@ -77,5 +81,8 @@ B = dict(
     k_noma_flush=E * (8 * V * V + 8 * V + 4),
     # batched policy (5-512-256): layer1 writes h1, heads reads the fc2 product; sample: heads + mask in, all outputs out
     k_policy_layer1=E * V * (20 + 4 * 512), k_policy_heads=E * V * (4 * 256 + 4 * (4 + V)),
-    k_policy_sample=E * V * (4 * (4 + V) + V + 8 + 4 * V + 4 * V + 12 + 4 * (V + 2)))
+    k_policy_sample=E * V * (4 * (4 + V) + V + 8 + 4 * V + 4 * V + 12 + 4 * (V + 2)),
+    # f4 episode meter: float64 accumulators read + written, the step's metrics / reward / power_w read
+    k_episode_clear=E * 8 * (17 + V), k_episode_accumulate=E * (16 * (17 + V) + 56 + 12 * V),
+    k_episode_summary=E * (8 * (17 + V) + 4 + 8 * 21))
 print(json.dumps(dict(E=E, V=V, M=M, reps=reps, algorithmic_bytes=B)))
