@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """The reference driver's rollout loop (marl_train_bcd.py:1244-1830, without the learner) with every
-stage on the GPU: batched SAC policies -> NOMA pairing -> fused RIS gains + step() -> replay ring.
+stage on the GPU: batched SAC policies -> NOMA pairing -> fused RIS gains + step() -> replay ring ->
+per-episode metrics (written as a TensorBoard event file under runs/rollout).
 
-    python examples/rollout.py [n_envs] [episodes]
+    python examples/rollout.py [n_envs] [episodes] [log_dir]
 
 Everything between the policy weights and the sampled training batch stays in HBM; the only host work
-per step is four kernel launches.  Needs an MI355X and the built librisvec.so."""
+per step is a handful of kernel launches.  Needs an MI355X and the built librisvec.so."""
 import os
 import sys
 import time
@@ -13,11 +14,12 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ris_vec_marl_amd import (BatchedPolicy, NomaGrouper, VecEnviron, VecReplayBuffer, apply_yaml_config,  # noqa: E402
-                              reference_lanes)
+from ris_vec_marl_amd import (BatchedPolicy, EpisodeMeter, NomaGrouper, ScalarSink, VecEnviron, VecReplayBuffer,  # noqa: E402
+                              apply_yaml_config, reference_lanes)
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 EPISODES = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+LOG_DIR = sys.argv[3] if len(sys.argv) > 3 else os.path.join("runs", "rollout")
 V, M, N_STEP, RIS_EVERY = 8, 40, 100, 100            # Config defaults of the driver (n_veh, M, steps, K_STEPS)
 
 L = reference_lanes()
@@ -28,12 +30,14 @@ env.make_new_game()
 policy = BatchedPolicy(V, 5, 512, 256, device="cuda:0")          # policy.load_agent_state_dict(i, sd) for trained weights
 grouper = NomaGrouper(env)
 memory = VecReplayBuffer(8 * N_STEP * E, 5, V + 2, V, device="cuda:0")
+meter, writer = EpisodeMeter(env), ScalarSink(LOG_DIR)           # the driver's ep_* sums and its SummaryWriter
 
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for ep in range(EPISODES):
     env.begin_episode(ep, env_refresh_every=5)
     grouper.begin_episode(ep)
+    meter.begin_episode()
     state_old = env.observe().clone()
     mask = None
     for st in range(N_STEP):
@@ -47,10 +51,14 @@ for ep in range(EPISODES):
         memory.store_batch(state_old, action_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"],
                            done=(st == N_STEP - 1), mask=mask if refreshed else None)
         state_old.copy_(env.tensors["obs"])
+        meter.accumulate(env)
     batch = memory.sample_buffer(256)               # what global_learn would consume
-    g = env.tensors["metrics"][:, 0]
-    print("episode %d: mean global reward %.3f, pairs/env %.2f, replay rows %d"
-          % (ep, float(g.mean()), float(V - grouper._t["n_groups"].float().mean()), min(memory.mem_cntr, memory.mem_size)))
+    sc = writer.write_episode(meter, ep)            # the driver's tags, mean over the envs
+    print("episode %d: global reward %.3f, delay %.2f ms, energy %.2e J, QoS violations %.1f %%, Jain %.3f, "
+          "pairs/env %.2f, replay rows %d"
+          % (ep, sc["reward/global_avg"], sc["abs/delay_ms"], sc["abs/energy_J"], 100 * sc["qos/violation_rate_ep_mean"],
+             sc["reward/jain"], float(V - grouper._t["n_groups"].float().mean()), min(memory.mem_cntr, memory.mem_size)))
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("%.2e env-steps/s over %d envs x %d steps" % (E * EPISODES * N_STEP / dt, E, EPISODES * N_STEP))
+writer.close()
+print("%.2e env-steps/s over %d envs x %d steps; scalars in %s" % (E * EPISODES * N_STEP / dt, E, EPISODES * N_STEP, writer.path))

@@ -261,3 +261,19 @@ def test_policy_abi_without_a_gpu():
     assert lib.risvec_policy_layer1(4, 8, 5, 512, None, None, None, None, None, None, None) == N.ERR_ARG
     assert lib.risvec_policy_heads(4, 8, 256, 12, None, None, None, None, None, None, None, None) == N.ERR_ARG
     assert lib.risvec_policy_heads(4, 8, 1024, 68, None, None, None, None, None, None, None, None) == N.ERR_SHAPE   # > 64 KB of LDS
+
+
+def test_episode_abi_without_a_gpu():
+    lib = N.load()
+    assert lib.risvec_episode_partial_rows(0) == 0 and lib.risvec_episode_partial_rows(1) == 1
+    assert lib.risvec_episode_partial_rows(256) == 1 and lib.risvec_episode_partial_rows(32768 + 1) == 129
+    assert lib.risvec_episode_clear(0, 8, None, None) == N.ERR_SHAPE
+    assert lib.risvec_episode_clear(4, 65, None, None) == N.ERR_SHAPE
+    assert lib.risvec_episode_clear(4, 8, None, None) == N.ERR_ARG and b"acc" in lib.risvec_last_error()
+    assert lib.risvec_episode_clear(1 << 27, 8, None, None) == N.ERR_SHAPE          # E * (17 + V) >= 2^31
+    assert lib.risvec_episode_accumulate(4, 8, None, None, None, 5.0, None, None) == N.ERR_ARG
+    assert lib.risvec_episode_accumulate(4, 8, 16, 16, None, 5.0, 8, None) == N.ERR_ARG      # acc not 16-byte aligned
+    assert lib.risvec_episode_accumulate(4, 8, 16, 16, None, -1.0, 16, None) == N.ERR_ARG and b"user_clip" in lib.risvec_last_error()
+    assert lib.risvec_episode_accumulate(4, 8, 16, 16, None, float("nan"), 16, None) == N.ERR_ARG
+    assert lib.risvec_episode_summary(4, 8, 0, 16, 16, None, 16, 16, None) == N.ERR_ARG and b"n_steps" in lib.risvec_last_error()
+    assert lib.risvec_episode_summary(4, 8, 3, 16, 16, None, None, 16, None) == N.ERR_ARG

@@ -35,6 +35,8 @@ b policy --policy --steps 300 --warmup 30
 b steer --steer
 b c5_steer --veh 16 --ris 256 --mode bcd --steps 300 --warmup 30 --steer
 b replay_steer --replay --steer
+b meter --meter
+b replay_meter --replay --meter
 echo "== streaming yardstick" | tee -a $OUT/round_$TAG.log
 timeout -k 10 300 python tools/membench.py > $OUT/membench_$TAG.jsonl 2>/dev/null; cat $OUT/membench_$TAG.jsonl
 echo "== 2-rank rehearsal on one GPU (gloo for the collective; RCCL needs one GPU per rank)" | tee -a $OUT/round_$TAG.log
