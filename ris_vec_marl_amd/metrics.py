@@ -102,6 +102,8 @@ class EpisodeMeter:
         def launch() -> None:
             check(fn(*args, stream))
             self.n_steps += 1
+
+        launch.keepalive = (metrics, reward, power_w)
         return launch
 
     def accumulate(self, env=None, metrics=None, reward=None, power_w=None) -> None:
