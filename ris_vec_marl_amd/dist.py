@@ -103,3 +103,19 @@ def gather_joint_obs(obs_local: torch.Tensor, group=None) -> torch.Tensor:
     out = g.start(obs_local)
     g.wait()
     return out
+
+
+def combine_episode_summary(summary: torch.Tensor, n_envs_local: int, group=None) -> torch.Tensor:
+    """`EpisodeMeter.summary` [3, C] (mean / min / max over this rank's envs) -> the same over the envs
+    of every rank: the mean weighted by the shard sizes, the min of mins, the max of maxes.  Three
+    C-element all-reduces once per EPISODE (the per-step path has no collective); the envs' own sums
+    never leave their GPU.  Returns a new tensor; a single process gets a copy."""
+    out = summary.clone()
+    if not td.is_initialized() or td.get_world_size(group) == 1:
+        return out
+    tot = torch.cat([summary[0] * float(n_envs_local), summary.new_tensor([float(n_envs_local)])])
+    td.all_reduce(tot, op=td.ReduceOp.SUM, group=group)
+    td.all_reduce(out[1], op=td.ReduceOp.MIN, group=group)
+    td.all_reduce(out[2], op=td.ReduceOp.MAX, group=group)
+    out[0] = tot[:-1] / tot[-1]
+    return out

@@ -34,20 +34,30 @@ def shard_obs(lo, hi):
     return o["obs"].astype(np.float32)
 
 
+def episode_summary(lo, hi):
+    """[3, 21] mean / min / max over envs lo..hi-1 of a fixed synthetic per-env table."""
+    per_env = torch.from_numpy(np.random.default_rng(11).normal(size=(E + 1, 21)))[lo:hi]
+    return torch.stack([per_env.mean(0), per_env.min(0).values, per_env.max(0).values])
+
+
 def worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from ris_vec_marl_amd import dist as rdist
     r, w, _ = rdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
+    lo, n = rdist.shard_range(E + 1, rank, world)
+    assert n == (33, 32)[rank]
+    summ_lo, summ_n = lo, n
     lo, n = rdist.shard_range(E, rank, world)
     obs_local = torch.from_numpy(shard_obs(lo, lo + n))
     g = rdist.JointObsGather(n, V, "cpu")
     a = g.start(obs_local); g.wait()
     b = g.start(obs_local * 2); g.wait()             # second buffer of the double buffer
     joint = rdist.gather_joint_obs(obs_local)
+    summ = rdist.combine_episode_summary(episode_summary(summ_lo, summ_lo + summ_n), summ_n)   # unequal shards: 33 + 32 envs
     if rank == 0:
-        out.put((a.numpy().copy(), b.numpy().copy(), joint.numpy().copy()))
+        out.put((a.numpy().copy(), b.numpy().copy(), joint.numpy().copy(), summ.numpy().copy()))
     td.barrier()
     td.destroy_process_group()
 
@@ -59,7 +69,7 @@ def test_joint_obs_allgather_world2():
     procs = [ctx.Process(target=worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    a, b, joint = out.get(timeout=120)
+    a, b, joint, summ = out.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -68,6 +78,9 @@ def test_joint_obs_allgather_world2():
     np.testing.assert_array_equal(a, whole)           # sharded == unsharded, bit for bit
     np.testing.assert_array_equal(b, whole * 2)
     np.testing.assert_array_equal(joint, whole)
+    want = episode_summary(0, E + 1).numpy()             # the episode summary of one rank owning every env
+    np.testing.assert_allclose(summ[0], want[0], rtol=1e-13, atol=1e-15)
+    np.testing.assert_array_equal(summ[1:], want[1:])
 
 
 def test_single_process_gather_is_a_copy():
@@ -75,3 +88,5 @@ def test_single_process_gather_is_a_copy():
     x = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)
     y = rdist.gather_joint_obs(x)
     assert y.shape == (2, 15) and torch.equal(y, x.reshape(2, 15))
+    s3 = torch.arange(63, dtype=torch.float64).reshape(3, 21)
+    assert torch.equal(rdist.combine_episode_summary(s3, 5), s3)
