@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 9
+#define RISVEC_ABI_VERSION 10
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -455,6 +455,15 @@ int risvec_policy_sample(int32_t n_envs, int32_t n_veh, int64_t env_offset, cons
  *           -> heads [V,E,H], the input of risvec_policy_sample                (F2 <= 1024) */
 int risvec_policy_layer1(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t f1, const float *obs, const float *W1,
                          const float *b1, const float *ln_w, const float *ln_b, float *out, risvec_stream_t stream);
+/* risvec_policy_layer1 writing the hidden row as the float16 operand of a split-precision GEMM: out16
+ * [V, E, 3*f1] halfs, row = [ hi(h) | hi(h) 2^-5 | (h - hi(h)) 2^6 ] with hi = round-to-nearest float16.
+ * Multiplied (float16 inputs, float32 accumulation) by the fc2 weight stacked along K as
+ * [ hi(W) ; (W - hi(W)) 2^5 ; hi(W) 2^-6 ] it gives h W to 2^-22 relative per product -- the accuracy of the
+ * float32 GEMM at the fp16 matrix-core rate.  f1 must be a multiple of 4, in_dims <= 8.  |h| must stay below
+ * the float16 maximum 65504 (LayerNorm outputs do). */
+int risvec_policy_layer1_split16(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t f1, const float *obs,
+                                 const float *W1, const float *b1, const float *ln_w, const float *ln_b, void *out16,
+                                 risvec_stream_t stream);
 int risvec_policy_heads(int32_t n_envs, int32_t n_veh, int32_t f2, int32_t n_heads, const float *g, const float *b2,
                         const float *ln_w, const float *ln_b, const float *Wh, const float *bh, float *heads,
                         risvec_stream_t stream);

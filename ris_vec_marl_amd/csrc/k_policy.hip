@@ -275,11 +275,19 @@ __device__ __forceinline__ void layer_norm_relu16(float4 (&x)[NT], int F, int c,
     }
 }
 
-template <int NT, int INMAX>
+// SPLIT16: instead of the float32 row, write the row as the three float16 K-blocks of the split product
+//     a.b ~= hi(a) hi(b) + hi(a) lo(b) + lo(a) hi(b),   hi = fp16(x), lo = x - hi  (|lo| <= 2^-11 |x|),
+// [ hi(a) | hi(a) 2^-5 | lo(a) 2^6 ], to be multiplied by [ hi(b) ; lo(b) 2^5 ; hi(b) 2^-6 ] in ONE fp16 GEMM with
+// float32 accumulation (K three times as long).  The power-of-two factors keep the low parts out of the
+// float16 subnormal range and cancel exactly; what is dropped, lo(a) lo(b) and the rounding of the low
+// parts, is 2^-22 relative per product -- float32-GEMM accuracy at the fp16 MFMA rate.
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+template <int NT, int INMAX, bool SPLIT16>
 __global__ void __launch_bounds__(kBlock)
 k_policy_layer1_v4(int E, int V, int IN, int F, const float* __restrict__ obs, const float* __restrict__ W1,
                    const float* __restrict__ b1, const float* __restrict__ lw, const float* __restrict__ lb,
-                   float* __restrict__ out, int iters) {
+                   void* __restrict__ out_any, int iters) {
     extern __shared__ float s_par[];                   // [IN + 3][F]: W1 rows, b1, ln weight, ln bias
     const int v = blockIdx.y;
     for (int i = threadIdx.x; i < IN * F; i += kBlock) s_par[i] = W1[(long long)v * IN * F + i];
@@ -317,9 +325,29 @@ k_policy_layer1_v4(int E, int V, int IN, int F, const float* __restrict__ obs, c
         }
         layer_norm_relu16<NT>(h, F, c, s_par + (IN + 1) * F, s_par + (IN + 2) * F);
         if (live) {
-            float* o = out + ((long long)v * E + e) * F;
+            if constexpr (SPLIT16) {
+                _Float16* o = static_cast<_Float16*>(out_any) + ((long long)v * E + e) * 3 * F;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { const int j = (c + 16 * t) * 4; if (j < F) *reinterpret_cast<float4*>(o + j) = h[t]; }
+                for (int t = 0; t < NT; ++t) {
+                    const int j = (c + 16 * t) * 4;
+                    if (j >= F) continue;
+                    const float x[4] = {h[t].x, h[t].y, h[t].z, h[t].w};
+                    half4_t hi, hs, lo;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        hi[k] = (_Float16)x[k];
+                        hs[k] = (_Float16)((float)hi[k] * 0.03125f);
+                        lo[k] = (_Float16)((x[k] - (float)hi[k]) * 64.0f);
+                    }
+                    *reinterpret_cast<half4_t*>(o + j) = hi;
+                    *reinterpret_cast<half4_t*>(o + F + j) = hs;
+                    *reinterpret_cast<half4_t*>(o + 2 * F + j) = lo;
+                }
+            } else {
+                float* o = static_cast<float*>(out_any) + ((long long)v * E + e) * F;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { const int j = (c + 16 * t) * 4; if (j < F) *reinterpret_cast<float4*>(o + j) = h[t]; }
+            }
         }
     }
 }
@@ -403,7 +431,7 @@ hipError_t launch_policy_layer1(int E, int V, int IN, int F, const float* obs, c
         const int iters = 4, rows_per_block = (kBlock / kWave) * 4 * iters;
         const dim3 grid((unsigned)((E + rows_per_block - 1) / rows_per_block), (unsigned)V);
         const size_t lds = (size_t)(IN + 3) * F * sizeof(float);
-#define RISVEC_L1V(N_) hipLaunchKernelGGL((k_policy_layer1_v4<N_, 8>), grid, dim3(kBlock), lds, st, E, V, IN, F, obs, W1, b1, lw, lb, out, iters)
+#define RISVEC_L1V(N_) hipLaunchKernelGGL((k_policy_layer1_v4<N_, 8, false>), grid, dim3(kBlock), lds, st, E, V, IN, F, obs, W1, b1, lw, lb, out, iters)
         switch (policy_nt(F)) {
             case 1: RISVEC_L1V(1); break;
             case 2: RISVEC_L1V(2); break;
@@ -427,6 +455,24 @@ hipError_t launch_policy_layer1(int E, int V, int IN, int F, const float* obs, c
         default: return hipErrorInvalidValue;
     }
 #undef RISVEC_L1
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_layer1_split16(int E, int V, int IN, int F, const float* obs, const float* W1, const float* b1,
+                                        const float* lw, const float* lb, void* out16, hipStream_t st) {
+    if (!(F % 4 == 0 && IN <= 8 && policy_nt(F) > 0)) return hipErrorInvalidValue;
+    const int iters = 4, rows_per_block = (kBlock / kWave) * 4 * iters;
+    const dim3 grid((unsigned)((E + rows_per_block - 1) / rows_per_block), (unsigned)V);
+    const size_t lds = (size_t)(IN + 3) * F * sizeof(float);
+#define RISVEC_L1S(N_) hipLaunchKernelGGL((k_policy_layer1_v4<N_, 8, true>), grid, dim3(kBlock), lds, st, E, V, IN, F, obs, W1, b1, lw, lb, out16, iters)
+    switch (policy_nt(F)) {
+        case 1: RISVEC_L1S(1); break;
+        case 2: RISVEC_L1S(2); break;
+        case 4: RISVEC_L1S(4); break;
+        case 8: RISVEC_L1S(8); break;
+        default: RISVEC_L1S(16); break;
+    }
+#undef RISVEC_L1S
     return hipGetLastError();
 }
 

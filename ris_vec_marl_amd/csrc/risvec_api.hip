@@ -498,6 +498,18 @@ int risvec_policy_layer1(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t
                                                    (hipStream_t)stream));
 }
 
+int risvec_policy_layer1_split16(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t f1, const float* obs,
+                                 const float* W1, const float* b1, const float* ln_w, const float* ln_b, void* out16,
+                                 risvec_stream_t stream) {
+    const char* fn = "risvec_policy_layer1_split16";
+    if (n_envs < 1 || n_veh < 1 || n_veh > 65535) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d n_veh=%d", fn, n_envs, n_veh);
+    if (in_dims < 1 || in_dims > 8 || f1 < 4 || f1 > 1024 || f1 % 4 != 0 || (long long)(in_dims + 3) * f1 * 4 > 64 * 1024)
+        return fail(RISVEC_ERR_SHAPE, "%s: in_dims=%d f1=%d (in_dims <= 8, f1 a multiple of 4 and <= 1024)", fn, in_dims, f1);
+    REQ_PTR(obs, "obs"); REQ_PTR(W1, "W1"); REQ_PTR(b1, "b1"); REQ_PTR(ln_w, "ln_w"); REQ_PTR(ln_b, "ln_b"); REQ_PTR(out16, "out16");
+    return finish(fn, risvec::launch_policy_layer1_split16(n_envs, n_veh, in_dims, f1, obs, W1, b1, ln_w, ln_b, out16,
+                                                           (hipStream_t)stream));
+}
+
 int risvec_policy_heads(int32_t n_envs, int32_t n_veh, int32_t f2, int32_t n_heads, const float* g, const float* b2,
                         const float* ln_w, const float* ln_b, const float* Wh, const float* bh, float* heads,
                         risvec_stream_t stream) {

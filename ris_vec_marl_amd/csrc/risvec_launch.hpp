@@ -68,6 +68,8 @@ hipError_t launch_policy_sample(int E, int V, long long env_offset, const float*
 
 hipError_t launch_policy_layer1(int E, int V, int IN, int F, const float* obs, const float* W1, const float* b1,
                                 const float* lw, const float* lb, float* out, hipStream_t st);
+hipError_t launch_policy_layer1_split16(int E, int V, int IN, int F, const float* obs, const float* W1, const float* b1,
+                                        const float* lw, const float* lb, void* out16, hipStream_t st);
 hipError_t launch_policy_heads(int E, int V, int F, int H, const float* g, const float* b2, const float* lw,
                                const float* lb, const float* Wh, const float* bh, float* heads, hipStream_t st);
 

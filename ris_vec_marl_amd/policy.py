@@ -30,8 +30,15 @@ class BatchedPolicy:
     """V stacked `PolicyNetwork`s (SAC:9-60): input_dims -> fc1 -> LayerNorm -> ReLU -> fc2 -> LayerNorm
     -> ReLU -> heads mu[n_actions], log_std[n_actions], intent_logits[n_agents]."""
 
+    GEMM_MODES = ("fp16x3", "fp32")
+
     def __init__(self, n_agents: int, input_dims: int = 5, fc1_dims: int = 512, fc2_dims: int = 256,
-                 n_actions: int = 2, device="cuda", seed: int = 0, env_offset: int = 0):
+                 n_actions: int = 2, device="cuda", seed: int = 0, env_offset: int = 0, gemm: Optional[str] = None):
+        """gemm: how the fc1 x fc2 product runs.  "fp32": a float32 library GEMM.  "fp16x3" (default when
+        fc1_dims is a multiple of 4 and input_dims <= 8): both operands split into float16 high and low
+        parts and the three significant partial products taken in ONE float16 GEMM with float32
+        accumulation (K three times as long) -- float32-GEMM accuracy (2^-22 per product) at the fp16
+        matrix-core rate; see `risvec_policy_layer1_split16`."""
         N.load()
         if n_actions != 2:
             raise ValueError("the reference's power head has 2 outputs (offload, local); got %d" % n_actions)
@@ -40,6 +47,11 @@ class BatchedPolicy:
             raise RuntimeError("ris_vec_marl_amd needs a HIP device; there is no CPU fallback")
         self.n_agents, self.input_dims, self.fc1_dims, self.fc2_dims = int(n_agents), int(input_dims), int(fc1_dims), int(fc2_dims)
         self.seed, self.env_offset, self._calls = int(seed), int(env_offset), 0
+        split_ok = self.fc1_dims % 4 == 0 and self.fc1_dims <= 1024 and self.input_dims <= 8
+        self.gemm = gemm if gemm is not None else ("fp16x3" if split_ok else "fp32")
+        if self.gemm not in self.GEMM_MODES or (self.gemm == "fp16x3" and not split_ok):
+            raise ValueError("gemm=%r (fp16x3 needs fc1_dims %% 4 == 0, fc1_dims <= 1024, input_dims <= 8)" % (gemm,))
+        self._w2_split = (None, None)                         # (key, [V, 3 fc1, fc2] float16)
         V, dev = self.n_agents, self.device
         g = torch.Generator(device="cpu").manual_seed(seed)
 
@@ -77,6 +89,15 @@ class BatchedPolicy:
         self.tau.fill_(float(tau))
         self.gumbel_hard.fill_(1 if gumbel_hard else 0)
 
+    def _split_w2(self) -> torch.Tensor:
+        """[ hi(W2) ; (W2 - hi(W2)) 2^5 ; hi(W2) 2^-6 ] along K as float16, rebuilt when W2 changes."""
+        key = (self.W2.data_ptr(), self.W2._version)
+        if self._w2_split[0] != key:
+            hi = self.W2.to(torch.float16)
+            lo = (self.W2 - hi.float()) * 32.0
+            self._w2_split = (key, torch.cat([hi, lo.to(torch.float16), (hi.float() * 0.015625).to(torch.float16)], 1).contiguous())
+        return self._w2_split[1]
+
     # ------------------------------------------------------------------ forward
     def forward_heads(self, obs: torch.Tensor) -> torch.Tensor:
         """SAC:62-78 for every agent: obs [E,V,input_dims] -> [V,E,4+V] rows (mu, log_std (unclamped),
@@ -86,11 +107,19 @@ class BatchedPolicy:
         E, V = int(obs.shape[0]), self.n_agents
         x = obs.to(self.device, torch.float32).contiguous()
         lib, stream = N.load(), torch.cuda.current_stream(self.device).cuda_stream
-        h1 = torch.empty(V, E, self.fc1_dims, device=self.device)
-        N.check(lib.risvec_policy_layer1(E, V, self.input_dims, self.fc1_dims, x.data_ptr(), self.W1.data_ptr(),
-                                         self.b1.data_ptr(), self.ln1_w.data_ptr(), self.ln1_b.data_ptr(), h1.data_ptr(),
-                                         stream))
-        g2 = torch.bmm(h1, self.W2)                              # [V,E,fc2]: library GEMM (its bias is added downstream)
+        if self.gemm == "fp16x3":
+            w2s = self._split_w2()
+            h1 = torch.empty(V, E, 3 * self.fc1_dims, dtype=torch.float16, device=self.device)
+            N.check(lib.risvec_policy_layer1_split16(E, V, self.input_dims, self.fc1_dims, x.data_ptr(), self.W1.data_ptr(),
+                                                     self.b1.data_ptr(), self.ln1_w.data_ptr(), self.ln1_b.data_ptr(),
+                                                     h1.data_ptr(), stream))
+            g2 = torch.bmm(h1, w2s, out_dtype=torch.float32)     # [V,E,fc2]: fp16 MFMA GEMM, float32 accumulate + output
+        else:
+            h1 = torch.empty(V, E, self.fc1_dims, device=self.device)
+            N.check(lib.risvec_policy_layer1(E, V, self.input_dims, self.fc1_dims, x.data_ptr(), self.W1.data_ptr(),
+                                             self.b1.data_ptr(), self.ln1_w.data_ptr(), self.ln1_b.data_ptr(), h1.data_ptr(),
+                                             stream))
+            g2 = torch.bmm(h1, self.W2)                          # [V,E,fc2]: library GEMM (its bias is added downstream)
         heads = torch.empty(V, E, 4 + V, device=self.device)
         N.check(lib.risvec_policy_heads(E, V, self.fc2_dims, 4 + V, g2.data_ptr(), self.b2.data_ptr(), self.ln2_w.data_ptr(),
                                         self.ln2_b.data_ptr(), self.Wh.data_ptr(), self.bh.data_ptr(), heads.data_ptr(),

@@ -277,3 +277,10 @@ def test_episode_abi_without_a_gpu():
     assert lib.risvec_episode_accumulate(4, 8, 16, 16, None, float("nan"), 16, None) == N.ERR_ARG
     assert lib.risvec_episode_summary(4, 8, 0, 16, 16, None, 16, 16, None) == N.ERR_ARG and b"n_steps" in lib.risvec_last_error()
     assert lib.risvec_episode_summary(4, 8, 3, 16, 16, None, None, 16, None) == N.ERR_ARG
+
+
+def test_policy_split16_abi_without_a_gpu():
+    lib = N.load()
+    assert lib.risvec_policy_layer1_split16(4, 8, 5, 510, None, None, None, None, None, None, None) == N.ERR_SHAPE
+    assert lib.risvec_policy_layer1_split16(4, 8, 9, 512, None, None, None, None, None, None, None) == N.ERR_SHAPE
+    assert lib.risvec_policy_layer1_split16(4, 8, 5, 512, None, None, None, None, None, None, None) == N.ERR_ARG

@@ -31,12 +31,14 @@ def agent_weights(d, a):
     return {k[len(pre):]: d[k] for k in d.files if k.startswith(pre)}
 
 
+@pytest.mark.parametrize("gemm", ["fp16x3", "fp32"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "policy_*.npz"))), ids=os.path.basename)
-def test_vs_golden(path):
+def test_vs_golden(path, gemm):
     from ris_vec_marl_amd import BatchedPolicy, marshal_actions
     d = np.load(path)
     V, B = int(d["V"]), int(d["B"])
-    pol = BatchedPolicy(V, 5, int(d["fc1"]), int(d["fc2"]), device=DEV)
+    pol = BatchedPolicy(V, 5, int(d["fc1"]), int(d["fc2"]), device=DEV, gemm=gemm)
+    assert pol.gemm == gemm
     for a in range(V):
         pol.load_agent_state_dict(a, agent_weights(d, a))
         pol.tau[a] = float(d["tau"][a])
@@ -131,14 +133,15 @@ def test_full_size_properties_and_philox():
         np.testing.assert_allclose(p[:, a, 1], np.tanh(n1 * np.exp(ls[:, 1]) + heads[a][:, 1]), atol=2e-4)
 
 
+@pytest.mark.parametrize("gemm", ["fp16x3", "fp32"])
 @pytest.mark.parametrize("dims", [(8, 512, 256), (4, 40, 24), (16, 128, 64), (3, 1000, 70)])
-def test_handwritten_forward_vs_library_forward(dims):
+def test_handwritten_forward_vs_library_forward(dims, gemm):
     """k_policy_layer1 / k_policy_heads (+ the rocBLAS fc2 GEMM) against the same forward done with library
     kernels only (torch.bmm + layer_norm), fp32 both: 1e-5 relative to the row scale."""
     from ris_vec_marl_amd import BatchedPolicy
     V, F1, F2 = dims
     E = 777
-    pol = BatchedPolicy(V, 5, F1, F2, device=DEV, seed=V)
+    pol = BatchedPolicy(V, 5, F1, F2, device=DEV, seed=V, gemm=gemm)
     with torch.no_grad():
         pol.Wh.mul_(50.0)
         pol.ln1_w.uniform_(0.5, 1.5); pol.ln1_b.uniform_(-0.2, 0.2); pol.ln2_w.uniform_(0.5, 1.5); pol.ln2_b.uniform_(-0.2, 0.2)
@@ -146,3 +149,51 @@ def test_handwritten_forward_vs_library_forward(dims):
     a, b = pol.forward_heads(obs), pol.forward_heads_torch(obs)
     scale = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-3)
     assert float(((a - b).abs() / scale).max()) < 2e-5
+
+
+def test_split_fp16_gemm_has_float32_accuracy():
+    """The fc1 x fc2 product as ONE float16 GEMM over the split operands (risvec_policy_layer1_split16 x
+    the stacked fc2 weight) against the float64 product of the same float32 hidden rows: its error is
+    of the order of the float32 library GEMM's, far below the 1e-5 bar; stale-weight cache and the
+    shapes the split form refuses.  (Weights below the float16 normal range, |w| < 6e-5, keep an ABSOLUTE
+    error of 2^-25 each -- irrelevant next to the other columns of the LayerNorm row they feed, which
+    is why the bound here is checked on weights of realistic size.)"""
+    from ris_vec_marl_amd import BatchedPolicy
+    from ris_vec_marl_amd import _native as N
+    V, F1, F2, E = 8, 512, 256, 2048
+    pol = BatchedPolicy(V, 5, F1, F2, device=DEV, seed=5)
+    assert pol.gemm == "fp16x3"
+    with torch.no_grad():
+        pol.ln1_w.uniform_(0.5, 3.0); pol.ln1_b.uniform_(-0.5, 0.5)
+        pol.W2.mul_(torch.logspace(-1.5, 1, F2, device=DEV))         # columns from small (2e-3) to large (0.6) weights
+    obs = torch.rand(E, V, 5, device=DEV) * 1.2
+    lib, st = N.load(), torch.cuda.current_stream().cuda_stream
+    h32 = torch.empty(V, E, F1, device=DEV)
+    N.check(lib.risvec_policy_layer1(E, V, 5, F1, obs.data_ptr(), pol.W1.data_ptr(), pol.b1.data_ptr(), pol.ln1_w.data_ptr(),
+                                     pol.ln1_b.data_ptr(), h32.data_ptr(), st))
+    h16 = torch.empty(V, E, 3 * F1, dtype=torch.float16, device=DEV)
+    N.check(lib.risvec_policy_layer1_split16(E, V, 5, F1, obs.data_ptr(), pol.W1.data_ptr(), pol.b1.data_ptr(),
+                                             pol.ln1_w.data_ptr(), pol.ln1_b.data_ptr(), h16.data_ptr(), st))
+    # the three K-blocks are what the header says, exactly
+    hi = h32.to(torch.float16)
+    assert torch.equal(h16[..., :F1], hi)
+    assert torch.equal(h16[..., F1:2 * F1], (hi.float() * 0.03125).to(torch.float16))
+    assert torch.equal(h16[..., 2 * F1:], ((h32 - hi.float()) * 64.0).to(torch.float16))
+    exact = torch.bmm(h32.double(), pol.W2.double())
+    split = torch.bmm(h16, pol._split_w2(), out_dtype=torch.float32).double()
+    plain = torch.bmm(h32, pol.W2).double()
+    scale = (h32.double().abs() @ pol.W2.double().abs()).clamp_min(1e-30)     # sum |a||b|: the natural error scale
+    e_split, e_plain = float(((split - exact).abs() / scale).max()), float(((plain - exact).abs() / scale).max())
+    assert e_split < 2e-6 and e_split < 8 * max(e_plain, 1e-7), (e_split, e_plain)
+    # the split weight follows in-place updates of W2
+    before = pol.forward_heads(obs).clone()
+    with torch.no_grad():
+        pol.W2.mul_(1.5)
+    after = pol.forward_heads(obs)
+    assert not torch.equal(before, after)
+    ref = pol.forward_heads_torch(obs)
+    assert float(((after - ref).abs() / ref.abs().amax(-1, keepdim=True).clamp_min(1e-3)).max()) < 2e-5
+    with pytest.raises(ValueError):
+        BatchedPolicy(2, 5, 30, 8, device=DEV, gemm="fp16x3")                 # fc1 not a multiple of 4
+    assert BatchedPolicy(2, 5, 30, 8, device=DEV).gemm == "fp32"
+    assert lib.risvec_policy_layer1_split16(4, 2, 5, 30, 16, 16, 16, 16, 16, 16, None) == N.ERR_SHAPE
