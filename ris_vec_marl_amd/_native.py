@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -157,6 +157,8 @@ _PROTOS = {
     "risvec_marshal_actions": (C.c_int, [C.c_int32, C.c_int32, _FP, _FP, C.c_float, _FP, _FP, _FP, _FP]),
     "risvec_policy_layer1": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "risvec_policy_layer1_split16": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "risvec_policy_mlp_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "risvec_policy_mlp": (C.c_int, [C.c_int32] * 6 + [_FP] * 14),
     "risvec_policy_heads": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "risvec_policy_sample": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _FP, _FP, _FP, _FP, _FP, _FP, C.c_uint64, C.c_uint32,
                                        C.c_float, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),

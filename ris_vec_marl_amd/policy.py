@@ -30,15 +30,19 @@ class BatchedPolicy:
     """V stacked `PolicyNetwork`s (SAC:9-60): input_dims -> fc1 -> LayerNorm -> ReLU -> fc2 -> LayerNorm
     -> ReLU -> heads mu[n_actions], log_std[n_actions], intent_logits[n_agents]."""
 
-    GEMM_MODES = ("fp16x3", "fp32")
+    GEMM_MODES = ("fused", "fp16x3", "fp32")
 
     def __init__(self, n_agents: int, input_dims: int = 5, fc1_dims: int = 512, fc2_dims: int = 256,
                  n_actions: int = 2, device="cuda", seed: int = 0, env_offset: int = 0, gemm: Optional[str] = None):
-        """gemm: how the fc1 x fc2 product runs.  "fp32": a float32 library GEMM.  "fp16x3" (default when
-        fc1_dims is a multiple of 4 and input_dims <= 8): both operands split into float16 high and low
-        parts and the three significant partial products taken in ONE float16 GEMM with float32
-        accumulation (K three times as long) -- float32-GEMM accuracy (2^-22 per product) at the fp16
-        matrix-core rate; see `risvec_policy_layer1_split16`."""
+        """gemm: how the forward runs.  "fp32": hand-written fc1 launch, float32 library GEMM for fc1 x fc2,
+        hand-written heads launch.  "fp16x3": the same three launches with both GEMM operands split into
+        float16 high and low parts and the three significant partial products taken in ONE float16 GEMM
+        with float32 accumulation (K three times as long) -- float32-GEMM accuracy (2^-22 per product) at
+        the fp16 matrix-core rate; see `risvec_policy_layer1_split16`.  "fused" (default where the kernel
+        is built for the shape: input_dims <= 5, fc1 % 16 == 0, fc2 in {128, 256}, 4 + n_agents <= 24):
+        the whole forward in one hand-written MFMA kernel with the same split product, the hidden layers
+        never leaving the chip (`risvec_policy_mlp`).  Default: the first of fused / fp16x3 / fp32 that
+        supports the shape."""
         N.load()
         if n_actions != 2:
             raise ValueError("the reference's power head has 2 outputs (offload, local); got %d" % n_actions)
@@ -48,10 +52,15 @@ class BatchedPolicy:
         self.n_agents, self.input_dims, self.fc1_dims, self.fc2_dims = int(n_agents), int(input_dims), int(fc1_dims), int(fc2_dims)
         self.seed, self.env_offset, self._calls = int(seed), int(env_offset), 0
         split_ok = self.fc1_dims % 4 == 0 and self.fc1_dims <= 1024 and self.input_dims <= 8
-        self.gemm = gemm if gemm is not None else ("fp16x3" if split_ok else "fp32")
-        if self.gemm not in self.GEMM_MODES or (self.gemm == "fp16x3" and not split_ok):
-            raise ValueError("gemm=%r (fp16x3 needs fc1_dims %% 4 == 0, fc1_dims <= 1024, input_dims <= 8)" % (gemm,))
+        fused_ok = bool(N.load().risvec_policy_mlp_supported(self.input_dims, self.fc1_dims, self.fc2_dims, 4 + self.n_agents))
+        self.gemm = gemm if gemm is not None else ("fused" if fused_ok else ("fp16x3" if split_ok else "fp32"))
+        if (self.gemm not in self.GEMM_MODES or (self.gemm == "fp16x3" and not split_ok)
+                or (self.gemm == "fused" and not fused_ok)):
+            raise ValueError("gemm=%r is not available for input_dims=%d fc1=%d fc2=%d n_agents=%d (fp16x3: fc1 %% 4 == 0 <= "
+                             "1024, input_dims <= 8; fused: input_dims <= 5, fc1 %% 16 == 0, fc2 in {128, 256}, n_agents <= 20)"
+                             % (gemm, self.input_dims, self.fc1_dims, self.fc2_dims, self.n_agents))
         self._w2_split = (None, None)                         # (key, [V, 3 fc1, fc2] float16)
+        self._fused_w = (None, None)                          # (key, (Wc, G, W2f))
         V, dev = self.n_agents, self.device
         g = torch.Generator(device="cpu").manual_seed(seed)
 
@@ -98,6 +107,39 @@ class BatchedPolicy:
             self._w2_split = (key, torch.cat([hi, lo.to(torch.float16), (hi.float() * 0.015625).to(torch.float16)], 1).contiguous())
         return self._w2_split[1]
 
+    def _fused_weights(self):
+        """(Wc, G, W2f, unscale, WhF, wh_unscale) of `risvec_policy_mlp`, rebuilt when W1 / b1 / ln1_w / W2 / Wh change: the fc1
+        weight centred over the feature axis (x LayerNorm-1 weight) with the 6 x 6 Gram matrix of the
+        centred rows (LayerNorm-1 statistics in closed form, float64 here), and the fc2 weight scaled by
+        a power of two, split into float16 hi + lo and laid out in MFMA fragment order."""
+        key = tuple((t.data_ptr(), t._version) for t in (self.W1, self.b1, self.ln1_w, self.W2, self.Wh))
+        if self._fused_w[0] != key:
+            V, IN, F1, F2 = self.n_agents, self.input_dims, self.fc1_dims, self.fc2_dims
+            wb = torch.cat([self.W1, self.b1], 1).double()                          # [V, IN+1, F1]
+            wc = torch.zeros(V, 6, F1, dtype=torch.float64, device=self.device)
+            wc[:, :IN + 1] = wb - wb.mean(-1, keepdim=True)
+            gram = torch.bmm(wc, wc.transpose(1, 2)) / F1
+            wcl = wc * self.ln1_w.double()
+            amax = self.W2.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+            shift = torch.floor(torch.log2(64.0 / amax)).clamp(0, 14)               # max |2^s W2| in [64, 128)
+            w2s = self.W2 * torch.exp2(shift)[:, None, None]
+            hi = w2s.to(torch.float16)
+            parts = torch.stack([hi, (w2s - hi.float()).to(torch.float16)], 1)     # [V, 2, F1, F2]
+            # (v, t, c, h, j, m, r) -> (v, c, t, m, h, r, j): lane = 32 h + r
+            frag = parts.reshape(V, 2, F1 // 16, 2, 8, F2 // 32, 32).permute(0, 2, 1, 5, 3, 6, 4).contiguous()
+            H = 4 + V
+            whp = torch.zeros(V, F2, 32, device=self.device)
+            whp[:, :, :H] = self.Wh
+            hshift = torch.floor(torch.log2(64.0 / self.Wh.abs().amax(dim=(1, 2)).clamp_min(1e-30))).clamp(0, 14)
+            whs = whp * torch.exp2(hshift)[:, None, None]
+            hhi = whs.to(torch.float16)
+            hparts = torch.stack([hhi, (whs - hhi.float()).to(torch.float16)], 1)   # [V, 2, F2, 32]
+            # feature f = 32 m + 16 u + 8 jh + 4 h + jl: (v, t, m, u, jh, h, jl, r) -> (v, m, u, t, h, r, jh, jl)
+            hfrag = hparts.reshape(V, 2, F2 // 32, 2, 2, 2, 4, 32).permute(0, 2, 3, 1, 5, 7, 4, 6).contiguous()
+            self._fused_w = (key, (wcl.float().contiguous(), gram.float().contiguous(), frag,
+                                   torch.exp2(-shift).float().contiguous(), hfrag, torch.exp2(-hshift).float().contiguous()))
+        return self._fused_w[1]
+
     # ------------------------------------------------------------------ forward
     def forward_heads(self, obs: torch.Tensor) -> torch.Tensor:
         """SAC:62-78 for every agent: obs [E,V,input_dims] -> [V,E,4+V] rows (mu, log_std (unclamped),
@@ -107,6 +149,14 @@ class BatchedPolicy:
         E, V = int(obs.shape[0]), self.n_agents
         x = obs.to(self.device, torch.float32).contiguous()
         lib, stream = N.load(), torch.cuda.current_stream(self.device).cuda_stream
+        if self.gemm == "fused":
+            wc, gram, frag, unscale, hfrag, hunscale = self._fused_weights()
+            heads = torch.empty(V, E, 4 + V, device=self.device)
+            N.check(lib.risvec_policy_mlp(E, V, self.input_dims, self.fc1_dims, self.fc2_dims, 4 + V, x.data_ptr(),
+                                          wc.data_ptr(), gram.data_ptr(), self.ln1_b.data_ptr(), frag.data_ptr(),
+                                          unscale.data_ptr(), self.b2.data_ptr(), self.ln2_w.data_ptr(), self.ln2_b.data_ptr(),
+                                          hfrag.data_ptr(), hunscale.data_ptr(), self.bh.data_ptr(), heads.data_ptr(), stream))
+            return heads
         if self.gemm == "fp16x3":
             w2s = self._split_w2()
             h1 = torch.empty(V, E, 3 * self.fc1_dims, dtype=torch.float16, device=self.device)

@@ -31,14 +31,14 @@ def agent_weights(d, a):
     return {k[len(pre):]: d[k] for k in d.files if k.startswith(pre)}
 
 
-@pytest.mark.parametrize("gemm", ["fp16x3", "fp32"])
+@pytest.mark.parametrize("gemm", ["default", "fp16x3", "fp32"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "policy_*.npz"))), ids=os.path.basename)
 def test_vs_golden(path, gemm):
     from ris_vec_marl_amd import BatchedPolicy, marshal_actions
     d = np.load(path)
     V, B = int(d["V"]), int(d["B"])
-    pol = BatchedPolicy(V, 5, int(d["fc1"]), int(d["fc2"]), device=DEV, gemm=gemm)
-    assert pol.gemm == gemm
+    pol = BatchedPolicy(V, 5, int(d["fc1"]), int(d["fc2"]), device=DEV, gemm=None if gemm == "default" else gemm)
+    assert pol.gemm == ("fp16x3" if gemm == "default" else gemm)      # 48/32 and 40/24 hidden units: no fused build
     for a in range(V):
         pol.load_agent_state_dict(a, agent_weights(d, a))
         pol.tau[a] = float(d["tau"][a])
@@ -133,14 +133,19 @@ def test_full_size_properties_and_philox():
         np.testing.assert_allclose(p[:, a, 1], np.tanh(n1 * np.exp(ls[:, 1]) + heads[a][:, 1]), atol=2e-4)
 
 
-@pytest.mark.parametrize("gemm", ["fp16x3", "fp32"])
-@pytest.mark.parametrize("dims", [(8, 512, 256), (4, 40, 24), (16, 128, 64), (3, 1000, 70)])
+@pytest.mark.parametrize("gemm", ["fused", "fp16x3", "fp32"])
+@pytest.mark.parametrize("dims", [(8, 512, 256), (4, 40, 24), (16, 128, 64), (3, 1000, 70), (16, 512, 256), (5, 48, 128),
+                                  (8, 1024, 256), (2, 16, 128)])
 def test_handwritten_forward_vs_library_forward(dims, gemm):
     """k_policy_layer1 / k_policy_heads (+ the rocBLAS fc2 GEMM) against the same forward done with library
     kernels only (torch.bmm + layer_norm), fp32 both: 1e-5 relative to the row scale."""
     from ris_vec_marl_amd import BatchedPolicy
     V, F1, F2 = dims
     E = 777
+    if gemm == "fused" and not (F1 % 16 == 0 and F2 in (128, 256)):
+        with pytest.raises(ValueError):
+            BatchedPolicy(V, 5, F1, F2, device=DEV, seed=V, gemm=gemm)
+        return
     pol = BatchedPolicy(V, 5, F1, F2, device=DEV, seed=V, gemm=gemm)
     with torch.no_grad():
         pol.Wh.mul_(50.0)
@@ -161,8 +166,7 @@ def test_split_fp16_gemm_has_float32_accuracy():
     from ris_vec_marl_amd import BatchedPolicy
     from ris_vec_marl_amd import _native as N
     V, F1, F2, E = 8, 512, 256, 2048
-    pol = BatchedPolicy(V, 5, F1, F2, device=DEV, seed=5)
-    assert pol.gemm == "fp16x3"
+    pol = BatchedPolicy(V, 5, F1, F2, device=DEV, seed=5, gemm="fp16x3")
     with torch.no_grad():
         pol.ln1_w.uniform_(0.5, 3.0); pol.ln1_b.uniform_(-0.5, 0.5)
         pol.W2.mul_(torch.logspace(-1.5, 1, F2, device=DEV))         # columns from small (2e-3) to large (0.6) weights
@@ -197,3 +201,33 @@ def test_split_fp16_gemm_has_float32_accuracy():
         BatchedPolicy(2, 5, 30, 8, device=DEV, gemm="fp16x3")                 # fc1 not a multiple of 4
     assert BatchedPolicy(2, 5, 30, 8, device=DEV).gemm == "fp32"
     assert lib.risvec_policy_layer1_split16(4, 2, 5, 30, 16, 16, 16, 16, 16, 16, None) == N.ERR_SHAPE
+
+
+def test_fused_mlp_edges_and_weight_updates():
+    """risvec_policy_mlp: row counts that leave partly empty wavefronts, zero observations (LayerNorm-1
+    variance from the bias row alone), a weight update picked up through the tensors' version counters,
+    20 heads (V = 16), and the driver's 512 / 256 sizes at E = 32 768 against the three-launch form."""
+    from ris_vec_marl_amd import BatchedPolicy
+    for (V, F1, F2, E) in ((8, 512, 256, 1), (8, 512, 256, 65), (16, 64, 128, 300), (3, 512, 256, 257)):
+        pol = BatchedPolicy(V, 5, F1, F2, device=DEV, seed=E)
+        assert pol.gemm == "fused"
+        with torch.no_grad():
+            pol.Wh.mul_(50.0); pol.ln1_w.uniform_(0.5, 1.5); pol.ln1_b.uniform_(-0.2, 0.2); pol.ln2_w.uniform_(0.5, 1.5)
+        obs = torch.rand(E, V, 5, device=DEV) * 1.2
+        obs[0] = 0.0
+        a, b = pol.forward_heads(obs), pol.forward_heads_torch(obs)
+        scale = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-3)
+        assert float(((a - b).abs() / scale).max()) < 2e-5, (V, F1, F2, E)
+        with torch.no_grad():
+            pol.W1.mul_(0.5); pol.b1.add_(0.1); pol.W2.mul_(1.25)
+        a2, b2 = pol.forward_heads(obs), pol.forward_heads_torch(obs)
+        assert not torch.equal(a, a2)
+        assert float(((a2 - b2).abs() / b2.abs().amax(dim=-1, keepdim=True).clamp_min(1e-3)).max()) < 2e-5
+    E, V = 32768, 8
+    pol = BatchedPolicy(V, 5, 512, 256, device=DEV, seed=1)
+    ref = BatchedPolicy(V, 5, 512, 256, device=DEV, seed=1, gemm="fp32")
+    with torch.no_grad():
+        pol.Wh.mul_(50.0); ref.Wh.mul_(50.0)
+    obs = torch.rand(E, V, 5, device=DEV) * 1.2
+    a, b = pol.forward_heads(obs), ref.forward_heads(obs)
+    assert float(((a - b).abs() / b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-3)).max()) < 2e-5
