@@ -464,28 +464,32 @@ int risvec_policy_layer1(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t
 int risvec_policy_layer1_split16(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t f1, const float *obs,
                                  const float *W1, const float *b1, const float *ln_w, const float *ln_b, void *out16,
                                  risvec_stream_t stream);
-/* The whole PolicyNetwork.forward (sac_agent.py:62-78) of every agent in ONE launch: fc1 + LayerNorm + ReLU
- * -> fc2 on the fp16 matrix cores (both operands split into float16 hi + lo, three partial products, float32
- * accumulation: float32 accuracy) -> LayerNorm + ReLU -> heads; neither hidden layer touches HBM.
- * Prepared weights (rebuild after an update):
- *   Wc  [V, 6, f1]  fc1 weight centred over the feature axis and multiplied by the LayerNorm-1 weight: row
- *                   i < in_dims = (W1[i,:] - mean(W1[i,:])) ln1_w, row in_dims = (b1 - mean(b1)) ln1_w, other rows 0;
- *   G   [V, 6, 6]   C C^T / f1 with C the centred rows WITHOUT ln1_w (LayerNorm-1 variance in closed form);
- *   W2f [V, f1/16, 2, f2/32, 64, 8] halfs, fragment order: element (c, t, m, lane, j) = S_t[16c + 8(lane>>5) + j]
- *                   [32m + (lane&31)] with S_0 = hi(2^s W2), S_1 = fp16(2^s W2 - S_0), W2 [f1, f2], s per agent such
- *                   that max |2^s W2| < 128 (keeps S_1 in the float16 normal range);
- *   w2_unscale [V]  2^-s;
- *   WhF [V, f2/32, 2, 2, 64, 8] halfs: the head weight Wh [f2, n_heads] (columns mu | log_std | intent_logits), scaled
- *                   and split the same way, zero-padded to 32 rows, in the k order in which the second MFMA reads the
- *                   first one's accumulator: element (m, u, t, lane, j) = S_t[32m + 16u + 8(j>>2) + 4(lane>>5) + (j&3)]
- *                   [lane&31];  wh_unscale [V] its 2^-s.
- * heads [V, E, n_heads].  Built for in_dims <= 5, f1 % 16 == 0 <= 1024, f2 in {128, 256}, n_heads <= 24
+/* The whole PolicyNetwork.forward (sac_agent.py:62-78) of every agent in ONE launch, all three layers on the
+ * fp16 matrix cores at float32 accuracy (every operand split into float16 hi + lo, the three significant partial
+ * products accumulated in float32); neither hidden layer touches HBM.  Prepared weights (rebuild after an update),
+ * "fragment" = the 8 halfs one lane feeds to v_mfma_f32_32x32x16_f16, S_0 = hi(2^s X), S_1 = fp16(2^s X - S_0), s a
+ * per-agent power of two that keeps S_1 in the float16 normal range:
+ *   G    [V, 6, 6]  C C^T / f1, C = fc1 weight rows (and the bias as row in_dims) centred over the feature axis:
+ *                   LayerNorm-1 variance of an env in closed form, var = x^T G x with x = (obs, 1, 0..);
+ *   fc1 operand     X = [f1, 16]: column k < in_dims = C[k] ln1_w, column in_dims = C[in_dims] ln1_w, column in_dims + 1
+ *                   = ln1_b, rest 0 (multiplied by (obs rstd, rstd, 1, 0..) it gives the normalised pre-activation);
+ *                   fragments of group g (32 features): element (t, lane, j) = S_t[32g + (lane&31)][8(lane>>5) + j];
+ *   W1F  [V, 2, 64, 8]  the fc1-operand fragments of group 0;
+ *   W2f  [V, f1/32, 8 + 4 f2/32, 64, 8]  the weight stream, per group g of 32 hidden features: 8 fragment rows holding
+ *                   the fc1-operand fragments of group g+1 (rows 0-1; rest padding), then for k-steps u = 0, 1 the
+ *                   fc2 weight X = W2 [f1, f2] in the k order in which the fc2 MFMA reads the fc1 MFMA's accumulator:
+ *                   rows [t][m], element (lane, j) = S_t[32g + 16u + 8(j>>2) + 4(lane>>5) + (j&3)][32m + (lane&31)];
+ *   w_unscale [V]   2^-(s_fc1 + s_fc2);
+ *   WhF  [V, f2/32, 2, 2, 64, 8]  X = the head weight Wh [f2, n_heads] (columns mu | log_std | intent_logits) zero-padded
+ *                   to 32 columns: element (m, u, t, lane, j) = S_t[32m + 16u + 8(j>>2) + 4(lane>>5) + (j&3)][lane&31];
+ *   wh_unscale [V]  its 2^-s.
+ * heads [V, E, n_heads].  Built for in_dims <= 5, f1 % 32 == 0 <= 1024, f2 in {128, 256}, n_heads <= 24
  * (risvec_policy_mlp_supported); other shapes return RISVEC_ERR_UNSUPPORTED -- use the three-launch form. */
 int risvec_policy_mlp_supported(int32_t in_dims, int32_t f1, int32_t f2, int32_t n_heads);
 int risvec_policy_mlp(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t f1, int32_t f2, int32_t n_heads, const float *obs,
-                      const float *Wc, const float *G, const float *ln1_b, const void *W2f, const float *w2_unscale,
-                      const float *b2, const float *ln2_w, const float *ln2_b, const void *WhF, const float *wh_unscale,
-                      const float *bh, float *heads, risvec_stream_t stream);
+                      const float *G, const void *W1F, const void *W2f, const float *w_unscale, const float *b2,
+                      const float *ln2_w, const float *ln2_b, const void *WhF, const float *wh_unscale, const float *bh,
+                      float *heads, risvec_stream_t stream);
 int risvec_policy_heads(int32_t n_envs, int32_t n_veh, int32_t f2, int32_t n_heads, const float *g, const float *b2,
                         const float *ln_w, const float *ln_b, const float *Wh, const float *bh, float *heads,
                         risvec_stream_t stream);

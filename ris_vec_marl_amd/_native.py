@@ -158,7 +158,7 @@ _PROTOS = {
     "risvec_policy_layer1": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "risvec_policy_layer1_split16": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "risvec_policy_mlp_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
-    "risvec_policy_mlp": (C.c_int, [C.c_int32] * 6 + [_FP] * 14),
+    "risvec_policy_mlp": (C.c_int, [C.c_int32] * 6 + [_FP] * 13),
     "risvec_policy_heads": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "risvec_policy_sample": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _FP, _FP, _FP, _FP, _FP, _FP, C.c_uint64, C.c_uint32,
                                        C.c_float, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),

@@ -10,11 +10,15 @@
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); the other half sits in lane ^ 32.  LayerNorm over
 // the features and the head GEMV are therefore in-register sums plus ONE cross-lane exchange.
 //
-// B operand, generated on the fly.  fc1 has K = input_dims (5): a lane computes the 8 hidden features
-// of its k-slot directly from the observation.  LayerNorm needs the row statistics first; fc1 being
-// linear they have a closed form: with the weights centred over the feature axis, Wc[i][f] = W1[i][f] -
-// mean_f W1[i] (bias as the row i = IN with x = 1), z_f - mean = sum_i x_i Wc[i][f] and var = x^T G x,
-// G = Wc Wc^T / F1 (a sum of squares: no cancellation).  Wc and G are prepared once per weight update.
+// B operand, generated on the fly -- by the matrix cores too.  LayerNorm needs the row statistics of the fc1
+// pre-activation first; fc1 being linear they have a closed form: with the weight centred over the feature
+// axis (bias as one more input row with x = 1), z_f - mean = sum_i x_i C[i][f] and var = x^T G x, G = C C^T / F1
+// (a sum of squares: no cancellation).  So the normalised, scaled and shifted pre-activation of 32 features is
+// ONE small product: rows of A = [C[0..IN-1][f] w_f, C[IN][f] w_f, b_f] (w, b the LayerNorm weight and bias),
+// columns of B = [x_0 rstd, .., x_{IN-1} rstd, rstd, 1] per env, K padded to 16.  Its result lands in the C/D
+// layout, i.e. with the features in registers and the env on the lane -- which is exactly the B-operand layout of
+// the next MFMA when the k order of the fc2 weight is chosen to match (registers 8u .. 8u+7 are k-step u): ReLU and
+// the float16 split are all the vector ALU has to do, and no fc1 weight is read by the vector path at all.
 //
 // Precision.  Both operands are split, x = hi + lo with hi = fp16(x), lo = fp16(x - hi), and the three
 // significant partial products hi.hi + hi.lo + lo.hi taken as three MFMAs per 16-feature chunk with float32
@@ -30,6 +34,8 @@
 // One wavefront per SIMD (256 accumulator registers per lane), so latency is hidden INSIDE the wavefront:
 // the B fragments of chunk c+1 are computed while the MFMAs of chunk c run (the group barriers lay the two
 // independent instruction streams out interleaved).
+#include <cstdlib>
+
 #include "risvec_launch.hpp"
 #include "risvec_step.hpp"
 
@@ -45,11 +51,11 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 struct MlpArgs {
     int E, V, IN, F1, H;
     const float* obs;        // [E,V,IN]
-    const float* Wc;         // [V,IN1,F1] centred fc1 weight x LayerNorm-1 weight, row IN = centred bias, rows above = 0
-    const float* G;          // [V,IN1,IN1] Gram matrix of the centred weight (without the LayerNorm weight) / F1
-    const float* ln1b;       // [V,F1]
-    const uint4* W2f;        // [V,F1/16,2,MT,64] 16-byte fragments of the scaled weight: hi, lo
-    const float* gscale;     // [V] 2^-S, undoes the weight scaling
+    const float* G;          // [V,6,6] Gram matrix of the centred fc1 rows / F1
+    const uint4* W1F;        // [V,2,64] 16-byte fragments of the fc1 operand of group 0 (scaled): hi, lo
+    const uint4* W2f;        // [V,F1/32,(8 + 4 MT) 64] the weight stream, per group of 32 hidden features: fc1 operand of the
+                             // NEXT group (hi, lo, 6 KiB of padding), then two chunks [hi|lo][MT][64] of the scaled fc2 weight
+    const float* gscale;     // [V] undoes the fc1 and fc2 weight scalings
     const float* b2; const float* ln2w; const float* ln2b;   // [V,F2]
     const uint4* WhF;        // [V,MT,2,2,64] 16-byte fragments of the scaled head weight (32 rows, zero padded): hi, lo
     const float* hscale;     // [V] undoes the head-weight scaling
@@ -58,149 +64,146 @@ struct MlpArgs {
 };
 
 constexpr float kLnEps = 1e-5f;
+constexpr int kIn1 = 6;      // input rows of G: up to 5 inputs + the bias row
 
-template <int MT, int NT, int IN1>
-__global__ void __launch_bounds__(kBlock)
+__device__ __forceinline__ void split16(const f32x8_t& y, half8_t& hi, half8_t& lo) {
+    hi = __builtin_convertvector(y, half8_t);
+    lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x8_t), half8_t);
+}
+
+constexpr int kMlpBlock = 512;       // 8 wavefronts = 2 per SIMD sharing one weight stream
+constexpr int kRing = 3;             // group slots in LDS: one being read, two in flight / landed
+
+template <int MT>
+__global__ void __launch_bounds__(kMlpBlock, 2)
 k_policy_mlp(MlpArgs A) {
     constexpr int F2 = 32 * MT;
-    constexpr int kChunkVec = 2 * MT * kWave;                 // uint4 per chunk
-    constexpr int kStage = kChunkVec / kBlock;                // uint4 per thread per chunk
-    static_assert(kChunkVec % kBlock == 0, "chunk must split evenly over the workgroup");
+    constexpr int kChunkVec = 2 * MT * kWave;                 // uint4 per chunk of 16 hidden features
+    constexpr int kGroupVec = 8 * kWave + 2 * kChunkVec;      // uint4 per group of 32: fc1 operand of the NEXT group (2 of 8 KiB used), 2 chunks
+    constexpr int kStage = kGroupVec / kMlpBlock;             // LDS-direct loads per wavefront per group
+    static_assert(kGroupVec % kMlpBlock == 0, "group must split evenly over the workgroup");
     extern __shared__ uint4 s_raw[];
-    uint4* s_a = s_raw;                                       // [2][2][MT][64]
-    float* s_wc = reinterpret_cast<float*>(s_a + 2 * kChunkVec);   // [IN1][F1]
-    const int F1 = A.F1, H = A.H;
-    float* s_l1 = s_wc + IN1 * F1;                            // [F1]: ln1 bias
-    float* s_p2 = s_l1 + F1;                                  // [3][F2]: b2, ln2 weight, bias
+    const int H = A.H, NG = A.F1 / 32;
+    uint4* s_ring = s_raw;                                    // [kRing][kGroupVec]
+    float* s_p2 = reinterpret_cast<float*>(s_ring + kRing * kGroupVec);   // [3][F2]: b2, ln2 weight, bias
     float* s_bh = s_p2 + 3 * F2;                              // [32]: head bias, zero padded
-    float* s_g = s_bh + 32;                                   // [IN1][IN1]
+    float* s_g = s_bh + 32;                                   // [6][6]
 
     const int v = blockIdx.y, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    for (int i = tid; i < IN1 * F1; i += kBlock) s_wc[i] = A.Wc[(size_t)v * IN1 * F1 + i];
-    for (int i = tid; i < F1; i += kBlock) s_l1[i] = A.ln1b[(size_t)v * F1 + i];
-    for (int i = tid; i < F2; i += kBlock) {
+    for (int i = tid; i < F2; i += kMlpBlock) {
         s_p2[i] = A.b2[(size_t)v * F2 + i]; s_p2[F2 + i] = A.ln2w[(size_t)v * F2 + i]; s_p2[2 * F2 + i] = A.ln2b[(size_t)v * F2 + i];
     }
-    for (int i = tid; i < 32; i += kBlock) s_bh[i] = i < H ? A.bh[(size_t)v * H + i] : 0.0f;
-    for (int i = tid; i < IN1 * IN1; i += kBlock) s_g[i] = A.G[(size_t)v * IN1 * IN1 + i];
-    const int NC = F1 / 16;
-    const uint4* wsrc = A.W2f + (size_t)v * NC * kChunkVec;
-#pragma unroll
-    for (int q = 0; q < kStage; ++q) s_a[q * kBlock + tid] = wsrc[q * kBlock + tid];
+    for (int i = tid; i < 32; i += kMlpBlock) s_bh[i] = i < H ? A.bh[(size_t)v * H + i] : 0.0f;
+    for (int i = tid; i < kIn1 * kIn1; i += kMlpBlock) s_g[i] = A.G[(size_t)v * kIn1 * kIn1 + i];
+    // the fc1 operand of group 0 goes to the head of the last slot (free until group 2 is staged)
+    if (tid < 2 * kWave) s_ring[(kRing - 1) * kGroupVec + tid] = A.W1F[(size_t)v * 2 * kWave + tid];
     __syncthreads();
 
-    // this lane's envs (one per N tile), their inputs and LayerNorm-1 scale
-    const long long row0 = ((long long)blockIdx.x * (kBlock / kWave) + wave) * (32 * NT);
-    float x[NT][IN1], rstd[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const long long e = row0 + 32 * n + r;
+    // this lane's env, its LayerNorm-1 scale, and the B operand of the fc1 product: [x rstd, rstd, 1, 0..] in the
+    // k-slots of the low lane half, zeros in the high half
+    const long long row0 = ((long long)blockIdx.x * (kMlpBlock / kWave) + wave) * 32;
+    const long long e = row0 + r;
+    half8_t xh, xl;
+    {
         const float* xin = A.obs + ((e < A.E ? e : 0) * A.V + v) * A.IN;
+        float x[kIn1];
 #pragma unroll
-        for (int i = 0; i < IN1; ++i) x[n][i] = i < A.IN ? xin[i < A.IN ? i : 0] : (i == A.IN ? 1.0f : 0.0f);
+        for (int i = 0; i < kIn1; ++i) x[i] = i < A.IN ? xin[i < A.IN ? i : 0] : (i == A.IN ? 1.0f : 0.0f);
         float var = 0.0f;
 #pragma unroll
-        for (int i = 0; i < IN1; ++i) {
+        for (int i = 0; i < kIn1; ++i) {
             float s = 0.0f;
 #pragma unroll
-            for (int k = 0; k < IN1; ++k) s = fmaf(s_g[i * IN1 + k], x[n][k], s);
-            var = fmaf(x[n][i], s, var);
+            for (int k = 0; k < kIn1; ++k) s = fmaf(s_g[i * kIn1 + k], x[k], s);
+            var = fmaf(x[i], s, var);
         }
-        rstd[n] = rsqrtf(fmaxf(var, 0.0f) + kLnEps);
+        const float rstd = rsqrtf(fmaxf(var, 0.0f) + kLnEps);
+        f32x8_t xb;
 #pragma unroll
-        for (int i = 0; i < IN1; ++i) x[n][i] *= rstd[n];        // the fc1 rows already carry the LayerNorm weight
+        for (int j = 0; j < 8; ++j) {
+            const float val = j < kIn1 ? x[j < kIn1 ? j : 0] * rstd : 0.0f;      // the bias row (x = 1) becomes rstd
+            xb[j] = h == 0 ? (j == A.IN + 1 ? 1.0f : val) : 0.0f;               // row IN+1 carries the LayerNorm bias
+        }
+        split16(xb, xh, xl);
     }
 
-    f32x16_t acc[MT][NT];
+    f32x16_t acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
+        for (int q = 0; q < 16; ++q) acc[m][q] = 0.0f;
 
-    // hidden features 16c + 8h .. +7 of this lane's k-slot for each of its envs, split into hi and lo
-    auto make_b = [&](int c, half8_t (&bf)[2][NT]) {
-        const int f0 = 16 * c + 8 * h;
-        f32x8_t wc[IN1];
+    // LayerNorm-1 output (before the ReLU) of 32 hidden features of this lane's env, C/D layout; w1 = its operand
+    auto layer1 = [&](const uint4* w1) {
+        const half8_t wh = __builtin_bit_cast(half8_t, w1[lane]);
+        const half8_t wl = __builtin_bit_cast(half8_t, w1[kWave + lane]);
+        f32x16_t d;
 #pragma unroll
-        for (int i = 0; i < IN1; ++i) wc[i] = *reinterpret_cast<const f32x8_t*>(s_wc + i * F1 + f0);
-        const f32x8_t lb = *reinterpret_cast<const f32x8_t*>(s_l1 + f0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            f32x8_t a = lb;
-#pragma unroll
-            for (int i = 0; i < IN1; ++i) a += wc[i] * x[n][i];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = fmaxf(a[j], 0.0f);
-            const half8_t hi = __builtin_convertvector(a, half8_t);
-            bf[0][n] = hi;
-            bf[1][n] = __builtin_convertvector(a - __builtin_convertvector(hi, f32x8_t), half8_t);
-        }
+        for (int q = 0; q < 16; ++q) d[q] = 0.0f;
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, d, 0, 0, 0);
+        return d;
     };
-
-    auto mfma_chunk = [&](const uint4* sa, const half8_t (&bf)[2][NT]) {
+    // registers 8u .. 8u+7 of it -> ReLU -> the split B fragments of k-step u
+    auto make_b = [&](const f32x16_t& d, int u, half8_t (&bf)[2]) {
+        f32x8_t y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = fmaxf(d[8 * u + j], 0.0f);
+        split16(y, bf[0], bf[1]);
+    };
+    const uint4* wsrc = A.W2f + (size_t)v * NG * kGroupVec;
+    auto stage = [&](int g) {                                 // group g of the weight stream, global -> LDS directly
+        const uint4* src = wsrc + (size_t)g * kGroupVec;
+        uint4* dst = s_ring + (g % kRing) * kGroupVec;
+#pragma unroll
+        for (int q = 0; q < kStage; ++q)
+            __builtin_amdgcn_global_load_lds((const gvoid_t*)(src + q * kMlpBlock + tid), (lvoid_t*)(dst + q * kMlpBlock + tid), 16, 0, 0);
+    };
+    auto mfma_chunk = [&](const uint4* sa, const half8_t (&bf)[2]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const half8_t ah = __builtin_bit_cast(half8_t, sa[m * kWave + lane]);
             const half8_t al = __builtin_bit_cast(half8_t, sa[(MT + m) * kWave + lane]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bf[0][n], acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bf[0][n], acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bf[1][n], acc[m][n], 0, 0, 0);
-            }
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bf[0], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bf[0], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bf[1], acc[m], 0, 0, 0);
         }
     };
 
-    half8_t bcur[2][NT], bnext[2][NT];
-    make_b(0, bcur);
-    int buf = 0;
-    for (int c = 0; c + 1 < NC; ++c) {
-        // fragments of the next chunk first: their LDS reads (fc1 weight, LayerNorm-1 bias) must precede the
-        // LDS-direct loads in program order, or the compiler, unable to tell the two LDS regions apart, drains
-        // the loads (s_waitcnt vmcnt(0)) before the first such read
-        make_b(c + 1, bnext);
-        {
-            const uint4* src = wsrc + (size_t)(c + 1) * kChunkVec;
-            uint4* sb = s_a + (buf ^ 1) * kChunkVec;
-#pragma unroll
-            for (int q = 0; q < kStage; ++q)
-                __builtin_amdgcn_global_load_lds((const gvoid_t*)(src + q * kBlock + tid), (lvoid_t*)(sb + q * kBlock + tid),
-                                                 16, 0, 0);
-        }
-        mfma_chunk(s_a + buf * kChunkVec, bcur);
-#pragma unroll
-        for (int i = 0; i < MT * NT; ++i) {                             // per 3 MFMAs: 2 LDS reads, 7 VALU
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bcur[t][n] = bnext[t][n];
-        __syncthreads();
-        buf ^= 1;
+    // The weight stream runs two groups ahead of the MFMAs (a chunk of MFMAs is shorter than an L2 round trip):
+    // slot g % 3 is read while g+1 and g+2 are in flight; counted waits leave the newest group outstanding across
+    // the barrier.  Raw s_barrier: __syncthreads() would drain the LDS-direct loads (vmcnt(0)).
+    f32x16_t d = layer1(s_ring + (kRing - 1) * kGroupVec);
+    stage(0);
+    if (NG > 1) stage(1);
+    if (NG > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStage) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    half8_t b0[2], b1[2];
+    for (int g = 0; g < NG; ++g) {
+        const uint4* slot = s_ring + (g % kRing) * kGroupVec;
+        make_b(d, 0, b0);
+        make_b(d, 1, b1);
+        if (g + 1 < NG) d = layer1(slot);                     // the next group's fc1 product: its operand came with this slot
+        if (g + 2 < NG) stage(g + 2);
+        mfma_chunk(slot + 8 * kWave, b0);
+        mfma_chunk(slot + 8 * kWave + kChunkVec, b1);
+        if (g + 2 < NG) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kStage) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
-    mfma_chunk(s_a + buf * kChunkVec, bcur);
 
     // ---- fc2 bias + LayerNorm + ReLU, in registers: this lane owns features 32m + (q & 3) + 8 (q >> 2) + 4h of its env
     // The head weight (fragment order, 4*MT KiB) takes over the staging buffers.
     __syncthreads();
     {
         const uint4* hsrc = A.WhF + (size_t)v * (4 * MT * kWave);
-        for (int i = tid; i < 4 * MT * kWave; i += kBlock) s_a[i] = hsrc[i];
+        for (int i = tid; i < 4 * MT * kWave; i += kMlpBlock) s_ring[i] = hsrc[i];
     }
     const float inv_f2 = 1.0f / (float)F2, unscale = A.gscale[v];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
+    {
         float s = 0.0f;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -210,8 +213,8 @@ k_policy_mlp(MlpArgs A) {
                 const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    acc[m][n][4 * g + k] = fmaf(acc[m][n][4 * g + k], unscale, bb[k]);
-                    s += acc[m][n][4 * g + k];
+                    acc[m][4 * g + k] = fmaf(acc[m][4 * g + k], unscale, bb[k]);
+                    s += acc[m][4 * g + k];
                 }
             }
         s += __shfl_xor(s, 32, kWave);
@@ -220,7 +223,7 @@ k_policy_mlp(MlpArgs A) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { const float d = acc[m][n][q] - mean; s2 = fmaf(d, d, s2); }
+            for (int q = 0; q < 16; ++q) { const float dd = acc[m][q] - mean; s2 = fmaf(dd, dd, s2); }
         s2 += __shfl_xor(s2, 32, kWave);
         const float rs = rsqrtf(s2 * inv_f2 + kLnEps);
 #pragma unroll
@@ -232,7 +235,7 @@ k_policy_mlp(MlpArgs A) {
                 const float ww[4] = {w.x, w.y, w.z, w.w}, bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    acc[m][n][4 * g + k] = fmaxf(fmaf((acc[m][n][4 * g + k] - mean) * rs, ww[k], bb[k]), 0.0f);
+                    acc[m][4 * g + k] = fmaxf(fmaf((acc[m][4 * g + k] - mean) * rs, ww[k], bb[k]), 0.0f);
             }
     }
     __syncthreads();
@@ -240,74 +243,74 @@ k_policy_mlp(MlpArgs A) {
     // ---- heads on the matrix cores: D[head][env] = Wh^T . y with the accumulator registers themselves as the B
     // operand (registers 8u .. 8u+7 of tile m are k-step (m, u); the head weight was laid out in that k order),
     // split hi + lo like the fc2 product
-    f32x16_t hacc[NT];
+    f32x16_t hacc;
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) hacc[n][q] = 0.0f;
+    for (int q = 0; q < 16; ++q) hacc[q] = 0.0f;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const half8_t wh = __builtin_bit_cast(half8_t, s_a[((m * 2 + u) * 2 + 0) * kWave + lane]);
-            const half8_t wl = __builtin_bit_cast(half8_t, s_a[((m * 2 + u) * 2 + 1) * kWave + lane]);
+            const half8_t wh = __builtin_bit_cast(half8_t, s_ring[((m * 2 + u) * 2 + 0) * kWave + lane]);
+            const half8_t wl = __builtin_bit_cast(half8_t, s_ring[((m * 2 + u) * 2 + 1) * kWave + lane]);
+            f32x8_t y;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                f32x8_t y;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) y[j] = acc[m][n][8 * u + j];
-                const half8_t yh = __builtin_convertvector(y, half8_t);
-                const half8_t yl = __builtin_convertvector(y - __builtin_convertvector(yh, f32x8_t), half8_t);
-                hacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, yh, hacc[n], 0, 0, 0);
-                hacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, yh, hacc[n], 0, 0, 0);
-                hacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, yl, hacc[n], 0, 0, 0);
-            }
+            for (int j = 0; j < 8; ++j) y[j] = acc[m][8 * u + j];
+            half8_t yh, yl;
+            split16(y, yh, yl);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, yh, hacc, 0, 0, 0);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, yh, hacc, 0, 0, 0);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, yl, hacc, 0, 0, 0);
         }
+    // head rows (q & 3) + 8 (q >> 2) + 4h: three groups of four consecutive heads per lane
     const float hs = A.hscale[v];
+    float outv[12];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const long long e = row0 + 32 * n + r;
-        if (e >= A.E) continue;
+    for (int q = 0; q < 12; ++q) outv[q] = fmaf(hacc[q], hs, s_bh[(q & 3) + 8 * (q >> 2) + 4 * h]);
+    if (e < A.E) {
         float* o = A.heads + ((size_t)v * A.E + e) * H;
 #pragma unroll
-        for (int q = 0; q < 12; ++q) {                           // head rows (q & 3) + 8 (q >> 2) + 4h < 24
-            const int hd = (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (hd < H) o[hd] = fmaf(hacc[n][q], hs, s_bh[hd]);
+        for (int gq = 0; gq < 3; ++gq) {
+            const int base = 8 * gq + 4 * h;
+            if ((H & 3) == 0 && base + 3 < H) {
+                *reinterpret_cast<float4*>(o + base) = make_float4(outv[4 * gq], outv[4 * gq + 1], outv[4 * gq + 2], outv[4 * gq + 3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (base + k < H) o[base + k] = outv[4 * gq + k];
+            }
         }
     }
 }
 
-template <int MT, int NT, int IN1>
+template <int MT>
 hipError_t launch_mlp(const MlpArgs& a, hipStream_t st) {
     const int F2 = 32 * MT;
-    const size_t lds = (size_t)2 * 2 * MT * kWave * sizeof(uint4)
-                       + ((size_t)IN1 * a.F1 + a.F1 + 3 * F2 + 32 + IN1 * IN1) * sizeof(float);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = k_policy_mlp<MT, NT, IN1>;
+    const size_t lds = (size_t)kRing * (8 * kWave + 4 * MT * kWave) * sizeof(uint4) + ((size_t)3 * F2 + 32 + kIn1 * kIn1) * sizeof(float);
+    auto kern = k_policy_mlp<MT>;
     if (lds > 64 * 1024) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
     }
-    const int rows = (kBlock / kWave) * 32 * NT;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((a.E + rows - 1) / rows), (unsigned)a.V), dim3(kBlock), lds, st, a);
+    const int rows = (kMlpBlock / kWave) * 32;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.E + rows - 1) / rows), (unsigned)a.V), dim3(kMlpBlock), lds, st, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-// Instantiated for the reference's shapes: input_dims <= 5, fc2 = 256 or 128, up to 24 heads (4 + V, V <= 20).  Anything else reports hipErrorInvalidValue and the caller uses the three-launch path.
+// Instantiated for the reference's shapes: input_dims <= 5, fc2 = 256 or 128, up to 24 heads (4 + V, V <= 20).
+// Anything else reports hipErrorInvalidValue and the caller uses the three-launch path.
 bool policy_mlp_supported(int IN, int F1, int F2, int H) {
-    return IN >= 1 && IN <= 5 && F1 >= 16 && F1 % 16 == 0 && F1 <= 1024 && (F2 == 256 || F2 == 128) && H >= 1 && H <= 24;
+    return IN >= 1 && IN <= 5 && F1 >= 32 && F1 % 32 == 0 && F1 <= 1024 && (F2 == 256 || F2 == 128) && H >= 1 && H <= 24;
 }
 
-hipError_t launch_policy_mlp(int E, int V, int IN, int F1, int F2, int H, const float* obs, const float* Wc, const float* G,
-                             const float* ln1b, const void* W2f, const float* gscale, const float* b2, const float* ln2w,
-                             const float* ln2b, const void* WhF, const float* hscale, const float* bh, float* heads,
-                             hipStream_t st) {
+hipError_t launch_policy_mlp(int E, int V, int IN, int F1, int F2, int H, const float* obs, const float* G, const void* W1F,
+                             const void* W2f, const float* gscale, const float* b2, const float* ln2w, const float* ln2b,
+                             const void* WhF, const float* hscale, const float* bh, float* heads, hipStream_t st) {
     if (!policy_mlp_supported(IN, F1, F2, H)) return hipErrorInvalidValue;
-    MlpArgs a{E, V, IN, F1, H, obs, Wc, G, ln1b, static_cast<const uint4*>(W2f), gscale, b2, ln2w, ln2b,
+    MlpArgs a{E, V, IN, F1, H, obs, G, static_cast<const uint4*>(W1F), static_cast<const uint4*>(W2f), gscale, b2, ln2w, ln2b,
               static_cast<const uint4*>(WhF), hscale, bh, heads};
-    return F2 == 256 ? launch_mlp<8, 2, 6>(a, st) : launch_mlp<4, 2, 6>(a, st);
+    return F2 == 256 ? launch_mlp<8>(a, st) : launch_mlp<4>(a, st);
 }
 
 }  // namespace risvec

@@ -515,20 +515,20 @@ int risvec_policy_mlp_supported(int32_t in_dims, int32_t f1, int32_t f2, int32_t
 }
 
 int risvec_policy_mlp(int32_t n_envs, int32_t n_veh, int32_t in_dims, int32_t f1, int32_t f2, int32_t n_heads, const float* obs,
-                      const float* Wc, const float* G, const float* ln1_b, const void* W2f, const float* w2_unscale,
-                      const float* b2, const float* ln2_w, const float* ln2_b, const void* WhF, const float* wh_unscale,
-                      const float* bh, float* heads, risvec_stream_t stream) {
+                      const float* G, const void* W1F, const void* W2f, const float* w_unscale, const float* b2,
+                      const float* ln2_w, const float* ln2_b, const void* WhF, const float* wh_unscale, const float* bh,
+                      float* heads, risvec_stream_t stream) {
     const char* fn = "risvec_policy_mlp";
     if (n_envs < 1 || n_veh < 1 || n_veh > 65535) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d n_veh=%d", fn, n_envs, n_veh);
     if (!risvec::policy_mlp_supported(in_dims, f1, f2, n_heads))
-        return fail(RISVEC_ERR_UNSUPPORTED, "%s: in_dims=%d f1=%d f2=%d n_heads=%d (built for in_dims <= 5, f1 a multiple of 16 "
+        return fail(RISVEC_ERR_UNSUPPORTED, "%s: in_dims=%d f1=%d f2=%d n_heads=%d (built for in_dims <= 5, f1 a multiple of 32 "
                     "and <= 1024, f2 = 128 or 256, n_heads <= 24; use risvec_policy_layer1 + a GEMM + risvec_policy_heads)", fn,
                     in_dims, f1, f2, n_heads);
-    REQ_PTR(obs, "obs"); REQ_PTR(Wc, "Wc"); REQ_PTR(G, "G"); REQ_PTR(ln1_b, "ln1_b"); REQ_PTR(W2f, "W2f");
-    REQ_PTR(w2_unscale, "w2_unscale"); REQ_PTR(b2, "b2"); REQ_PTR(ln2_w, "ln2_w"); REQ_PTR(ln2_b, "ln2_b"); REQ_PTR(WhF, "WhF"); REQ_PTR(wh_unscale, "wh_unscale");
+    REQ_PTR(obs, "obs"); REQ_PTR(G, "G"); REQ_PTR(W1F, "W1F"); REQ_PTR(W2f, "W2f"); REQ_PTR(w_unscale, "w_unscale");
+    REQ_PTR(b2, "b2"); REQ_PTR(ln2_w, "ln2_w"); REQ_PTR(ln2_b, "ln2_b"); REQ_PTR(WhF, "WhF"); REQ_PTR(wh_unscale, "wh_unscale");
     REQ_PTR(bh, "bh"); REQ_PTR(heads, "heads");
-    return finish(fn, risvec::launch_policy_mlp(n_envs, n_veh, in_dims, f1, f2, n_heads, obs, Wc, G, ln1_b, W2f, w2_unscale, b2,
-                                                ln2_w, ln2_b, WhF, wh_unscale, bh, heads, (hipStream_t)stream));
+    return finish(fn, risvec::launch_policy_mlp(n_envs, n_veh, in_dims, f1, f2, n_heads, obs, G, W1F, W2f, w_unscale, b2, ln2_w,
+                                                ln2_b, WhF, wh_unscale, bh, heads, (hipStream_t)stream));
 }
 
 int risvec_policy_heads(int32_t n_envs, int32_t n_veh, int32_t f2, int32_t n_heads, const float* g, const float* b2,

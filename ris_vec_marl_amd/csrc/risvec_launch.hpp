@@ -71,10 +71,9 @@ hipError_t launch_policy_layer1(int E, int V, int IN, int F, const float* obs, c
 hipError_t launch_policy_layer1_split16(int E, int V, int IN, int F, const float* obs, const float* W1, const float* b1,
                                         const float* lw, const float* lb, void* out16, hipStream_t st);
 bool policy_mlp_supported(int IN, int F1, int F2, int H);
-hipError_t launch_policy_mlp(int E, int V, int IN, int F1, int F2, int H, const float* obs, const float* Wc, const float* G,
-                             const float* ln1b, const void* W2f, const float* gscale, const float* b2, const float* ln2w,
-                             const float* ln2b, const void* WhF, const float* hscale, const float* bh, float* heads,
-                             hipStream_t st);
+hipError_t launch_policy_mlp(int E, int V, int IN, int F1, int F2, int H, const float* obs, const float* G, const void* W1F,
+                             const void* W2f, const float* gscale, const float* b2, const float* ln2w, const float* ln2b,
+                             const void* WhF, const float* hscale, const float* bh, float* heads, hipStream_t st);
 hipError_t launch_policy_heads(int E, int V, int F, int H, const float* g, const float* b2, const float* lw,
                                const float* lb, const float* Wh, const float* bh, float* heads, hipStream_t st);
 

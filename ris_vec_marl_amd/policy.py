@@ -39,7 +39,7 @@ class BatchedPolicy:
         float16 high and low parts and the three significant partial products taken in ONE float16 GEMM
         with float32 accumulation (K three times as long) -- float32-GEMM accuracy (2^-22 per product) at
         the fp16 matrix-core rate; see `risvec_policy_layer1_split16`.  "fused" (default where the kernel
-        is built for the shape: input_dims <= 5, fc1 % 16 == 0, fc2 in {128, 256}, 4 + n_agents <= 24):
+        is built for the shape: input_dims <= 5, fc1 % 32 == 0, fc2 in {128, 256}, 4 + n_agents <= 24):
         the whole forward in one hand-written MFMA kernel with the same split product, the hidden layers
         never leaving the chip (`risvec_policy_mlp`).  Default: the first of fused / fp16x3 / fp32 that
         supports the shape."""
@@ -57,7 +57,7 @@ class BatchedPolicy:
         if (self.gemm not in self.GEMM_MODES or (self.gemm == "fp16x3" and not split_ok)
                 or (self.gemm == "fused" and not fused_ok)):
             raise ValueError("gemm=%r is not available for input_dims=%d fc1=%d fc2=%d n_agents=%d (fp16x3: fc1 %% 4 == 0 <= "
-                             "1024, input_dims <= 8; fused: input_dims <= 5, fc1 %% 16 == 0, fc2 in {128, 256}, n_agents <= 20)"
+                             "1024, input_dims <= 8; fused: input_dims <= 5, fc1 %% 32 == 0, fc2 in {128, 256}, n_agents <= 20)"
                              % (gemm, self.input_dims, self.fc1_dims, self.fc2_dims, self.n_agents))
         self._w2_split = (None, None)                         # (key, [V, 3 fc1, fc2] float16)
         self._fused_w = (None, None)                          # (key, (Wc, G, W2f))
@@ -107,37 +107,51 @@ class BatchedPolicy:
             self._w2_split = (key, torch.cat([hi, lo.to(torch.float16), (hi.float() * 0.015625).to(torch.float16)], 1).contiguous())
         return self._w2_split[1]
 
+    @staticmethod
+    def _split_scaled(w: torch.Tensor, target: float):
+        """(hi, lo, 2^-s): w 2^s with its largest entry in [target, 2 target) per agent, split into float16
+        hi + lo (the scaling keeps lo in the float16 normal range; powers of two cancel exactly)."""
+        amax = w.abs().amax(dim=tuple(range(1, w.dim()))).clamp_min(1e-30)
+        shift = torch.floor(torch.log2(target / amax)).clamp(-14, 14)
+        ws = w.float() * torch.exp2(shift).reshape(-1, *([1] * (w.dim() - 1)))
+        hi = ws.to(torch.float16)
+        return hi, (ws - hi.float()).to(torch.float16), torch.exp2(-shift).float()
+
     def _fused_weights(self):
-        """(Wc, G, W2f, unscale, WhF, wh_unscale) of `risvec_policy_mlp`, rebuilt when W1 / b1 / ln1_w / W2 / Wh change: the fc1
-        weight centred over the feature axis (x LayerNorm-1 weight) with the 6 x 6 Gram matrix of the
-        centred rows (LayerNorm-1 statistics in closed form, float64 here), and the fc2 weight scaled by
-        a power of two, split into float16 hi + lo and laid out in MFMA fragment order."""
-        key = tuple((t.data_ptr(), t._version) for t in (self.W1, self.b1, self.ln1_w, self.W2, self.Wh))
+        """(G, W1F, W2f, unscale, WhF, wh_unscale) of `risvec_policy_mlp` (layouts: include/risvec.h), rebuilt
+        when a weight changes: the Gram matrix of the centred fc1 rows (LayerNorm-1 statistics in closed
+        form, float64 here), and the three layers' weights scaled, split into float16 hi + lo and laid out in
+        MFMA fragment order."""
+        key = tuple((t.data_ptr(), t._version) for t in (self.W1, self.b1, self.ln1_w, self.ln1_b, self.W2, self.Wh))
         if self._fused_w[0] != key:
-            V, IN, F1, F2 = self.n_agents, self.input_dims, self.fc1_dims, self.fc2_dims
+            V, IN, F1, F2, dev = self.n_agents, self.input_dims, self.fc1_dims, self.fc2_dims, self.device
             wb = torch.cat([self.W1, self.b1], 1).double()                          # [V, IN+1, F1]
-            wc = torch.zeros(V, 6, F1, dtype=torch.float64, device=self.device)
+            wc = torch.zeros(V, 6, F1, dtype=torch.float64, device=dev)
             wc[:, :IN + 1] = wb - wb.mean(-1, keepdim=True)
             gram = torch.bmm(wc, wc.transpose(1, 2)) / F1
-            wcl = wc * self.ln1_w.double()
-            amax = self.W2.abs().amax(dim=(1, 2)).clamp_min(1e-30)
-            shift = torch.floor(torch.log2(64.0 / amax)).clamp(0, 14)               # max |2^s W2| in [64, 128)
-            w2s = self.W2 * torch.exp2(shift)[:, None, None]
-            hi = w2s.to(torch.float16)
-            parts = torch.stack([hi, (w2s - hi.float()).to(torch.float16)], 1)     # [V, 2, F1, F2]
-            # (v, t, c, h, j, m, r) -> (v, c, t, m, h, r, j): lane = 32 h + r
-            frag = parts.reshape(V, 2, F1 // 16, 2, 8, F2 // 32, 32).permute(0, 2, 1, 5, 3, 6, 4).contiguous()
-            H = 4 + V
-            whp = torch.zeros(V, F2, 32, device=self.device)
-            whp[:, :, :H] = self.Wh
-            hshift = torch.floor(torch.log2(64.0 / self.Wh.abs().amax(dim=(1, 2)).clamp_min(1e-30))).clamp(0, 14)
-            whs = whp * torch.exp2(hshift)[:, None, None]
-            hhi = whs.to(torch.float16)
-            hparts = torch.stack([hhi, (whs - hhi.float()).to(torch.float16)], 1)   # [V, 2, F2, 32]
+            # fc1 + LayerNorm-1 operand [V, F1, 16]
+            op1 = torch.zeros(V, F1, 16, dtype=torch.float64, device=dev)
+            op1[:, :, :IN + 1] = (wc[:, :IN + 1] * self.ln1_w.double()).transpose(1, 2)
+            op1[:, :, IN + 1] = self.ln1_b.double()[:, 0]
+            h1, l1, u1 = self._split_scaled(op1.float(), 16.0)
+            # (v, t, g, r, h, j) -> (v, g, t, h, r, j): lane = 32 h + r
+            w1f = torch.stack([h1, l1], 1).reshape(V, 2, F1 // 32, 32, 2, 8).permute(0, 2, 1, 4, 3, 5).reshape(V, F1 // 32, 2, 64, 8)
+            h2, l2, u2 = self._split_scaled(self.W2, 64.0)
+            # hidden feature f = 32 g + 16 u + 8 jh + 4 h + jl: (v, t, g, u, jh, h, jl, m, r) -> (v, g, u, t, m, h, r, jh, jl)
+            frag = torch.stack([h2, l2], 1).reshape(V, 2, F1 // 32, 2, 2, 2, 4, F2 // 32, 32) \
+                .permute(0, 2, 3, 1, 7, 5, 8, 4, 6).contiguous()
+            whp = torch.zeros(V, F2, 32, device=dev)
+            whp[:, :, :4 + V] = self.Wh
+            hh, hl, uh = self._split_scaled(whp, 64.0)
             # feature f = 32 m + 16 u + 8 jh + 4 h + jl: (v, t, m, u, jh, h, jl, r) -> (v, m, u, t, h, r, jh, jl)
-            hfrag = hparts.reshape(V, 2, F2 // 32, 2, 2, 2, 4, 32).permute(0, 2, 3, 1, 5, 7, 4, 6).contiguous()
-            self._fused_w = (key, (wcl.float().contiguous(), gram.float().contiguous(), frag,
-                                   torch.exp2(-shift).float().contiguous(), hfrag, torch.exp2(-hshift).float().contiguous()))
+            hfrag = torch.stack([hh, hl], 1).reshape(V, 2, F2 // 32, 2, 2, 2, 4, 32).permute(0, 2, 3, 1, 5, 7, 4, 6).contiguous()
+            # the weight stream, per group of 32 hidden features: fc1 operand of the NEXT group (8 KiB slot), two chunks
+            MT, NG = F2 // 32, F1 // 32
+            stream = torch.zeros(V, NG, 8 + 4 * MT, 64, 8, dtype=torch.float16, device=dev)
+            stream[:, :-1, 0:2] = w1f[:, 1:]
+            stream[:, :, 8:] = frag.reshape(V, NG, 4 * MT, 64, 8)
+            self._fused_w = (key, (gram.float().contiguous(), w1f[:, 0].contiguous(), stream, (u1 * u2).contiguous(), hfrag,
+                                   uh.contiguous()))
         return self._fused_w[1]
 
     # ------------------------------------------------------------------ forward
@@ -150,12 +164,12 @@ class BatchedPolicy:
         x = obs.to(self.device, torch.float32).contiguous()
         lib, stream = N.load(), torch.cuda.current_stream(self.device).cuda_stream
         if self.gemm == "fused":
-            wc, gram, frag, unscale, hfrag, hunscale = self._fused_weights()
+            gram, w1f, frag, unscale, hfrag, hunscale = self._fused_weights()
             heads = torch.empty(V, E, 4 + V, device=self.device)
             N.check(lib.risvec_policy_mlp(E, V, self.input_dims, self.fc1_dims, self.fc2_dims, 4 + V, x.data_ptr(),
-                                          wc.data_ptr(), gram.data_ptr(), self.ln1_b.data_ptr(), frag.data_ptr(),
-                                          unscale.data_ptr(), self.b2.data_ptr(), self.ln2_w.data_ptr(), self.ln2_b.data_ptr(),
-                                          hfrag.data_ptr(), hunscale.data_ptr(), self.bh.data_ptr(), heads.data_ptr(), stream))
+                                          gram.data_ptr(), w1f.data_ptr(), frag.data_ptr(), unscale.data_ptr(),
+                                          self.b2.data_ptr(), self.ln2_w.data_ptr(), self.ln2_b.data_ptr(), hfrag.data_ptr(),
+                                          hunscale.data_ptr(), self.bh.data_ptr(), heads.data_ptr(), stream))
             return heads
         if self.gemm == "fp16x3":
             w2s = self._split_w2()

@@ -134,15 +134,15 @@ def test_full_size_properties_and_philox():
 
 
 @pytest.mark.parametrize("gemm", ["fused", "fp16x3", "fp32"])
-@pytest.mark.parametrize("dims", [(8, 512, 256), (4, 40, 24), (16, 128, 64), (3, 1000, 70), (16, 512, 256), (5, 48, 128),
-                                  (8, 1024, 256), (2, 16, 128)])
+@pytest.mark.parametrize("dims", [(8, 512, 256), (4, 40, 24), (16, 128, 64), (3, 1000, 70), (16, 512, 256), (5, 96, 128),
+                                  (8, 1024, 256), (2, 32, 128)])
 def test_handwritten_forward_vs_library_forward(dims, gemm):
     """k_policy_layer1 / k_policy_heads (+ the rocBLAS fc2 GEMM) against the same forward done with library
     kernels only (torch.bmm + layer_norm), fp32 both: 1e-5 relative to the row scale."""
     from ris_vec_marl_amd import BatchedPolicy
     V, F1, F2 = dims
     E = 777
-    if gemm == "fused" and not (F1 % 16 == 0 and F2 in (128, 256)):
+    if gemm == "fused" and not (F1 % 32 == 0 and F2 in (128, 256)):
         with pytest.raises(ValueError):
             BatchedPolicy(V, 5, F1, F2, device=DEV, seed=V, gemm=gemm)
         return
