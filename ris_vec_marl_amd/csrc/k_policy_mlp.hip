@@ -175,6 +175,8 @@ k_policy_mlp(MlpArgs A) {
     // The weight stream runs two groups ahead of the MFMAs (a chunk of MFMAs is shorter than an L2 round trip):
     // slot g % 3 is read while g+1 and g+2 are in flight; counted waits leave the newest group outstanding across
     // the barrier.  Raw s_barrier: __syncthreads() would drain the LDS-direct loads (vmcnt(0)).
+    const uint4* hsrc = A.WhF + (size_t)v * (4 * MT * kWave);
+    uint4* s_heads = s_ring + (NG % kRing) * kGroupVec;       // free from the last group on
     f32x16_t d = layer1(s_ring + (kRing - 1) * kGroupVec);
     stage(0);
     if (NG > 1) stage(1);
@@ -185,10 +187,15 @@ k_policy_mlp(MlpArgs A) {
     for (int g = 0; g < NG; ++g) {
         const uint4* slot = s_ring + (g % kRing) * kGroupVec;
         make_b(d, 0, b0);
-        make_b(d, 1, b1);
-        if (g + 1 < NG) d = layer1(slot);                     // the next group's fc1 product: its operand came with this slot
-        if (g + 2 < NG) stage(g + 2);
+        if (g + 2 < NG) {
+            stage(g + 2);
+        } else if (g + 1 == NG) {                             // last group: the head weight rides in on the free slot
+            for (int i = tid; i < 4 * MT * kWave; i += kMlpBlock)
+                __builtin_amdgcn_global_load_lds((const gvoid_t*)(hsrc + i), (lvoid_t*)(s_heads + i), 16, 0, 0);
+        }
         mfma_chunk(slot + 8 * kWave, b0);
+        make_b(d, 1, b1);                                     // beside chunk 0's MFMAs
+        if (g + 1 < NG) d = layer1(slot);                     // the next group's fc1 product: its operand came with this slot
         mfma_chunk(slot + 8 * kWave + kChunkVec, b1);
         if (g + 2 < NG) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kStage) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -196,12 +203,6 @@ k_policy_mlp(MlpArgs A) {
     }
 
     // ---- fc2 bias + LayerNorm + ReLU, in registers: this lane owns features 32m + (q & 3) + 8 (q >> 2) + 4h of its env
-    // The head weight (fragment order, 4*MT KiB) takes over the staging buffers.
-    __syncthreads();
-    {
-        const uint4* hsrc = A.WhF + (size_t)v * (4 * MT * kWave);
-        for (int i = tid; i < 4 * MT * kWave; i += kMlpBlock) s_ring[i] = hsrc[i];
-    }
     const float inv_f2 = 1.0f / (float)F2, unscale = A.gscale[v];
     {
         float s = 0.0f;
@@ -238,7 +239,6 @@ k_policy_mlp(MlpArgs A) {
                     acc[m][4 * g + k] = fmaxf(fmaf((acc[m][4 * g + k] - mean) * rs, ww[k], bb[k]), 0.0f);
             }
     }
-    __syncthreads();
 
     // ---- heads on the matrix cores: D[head][env] = Wh^T . y with the accumulator registers themselves as the B
     // operand (registers 8u .. 8u+7 of tile m are k-step (m, u); the head weight was laid out in that k order),
@@ -250,8 +250,8 @@ k_policy_mlp(MlpArgs A) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const half8_t wh = __builtin_bit_cast(half8_t, s_ring[((m * 2 + u) * 2 + 0) * kWave + lane]);
-            const half8_t wl = __builtin_bit_cast(half8_t, s_ring[((m * 2 + u) * 2 + 1) * kWave + lane]);
+            const half8_t wh = __builtin_bit_cast(half8_t, s_heads[((m * 2 + u) * 2 + 0) * kWave + lane]);
+            const half8_t wl = __builtin_bit_cast(half8_t, s_heads[((m * 2 + u) * 2 + 1) * kWave + lane]);
             f32x8_t y;
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = acc[m][8 * u + j];
