@@ -108,11 +108,13 @@ class BatchedPolicy:
         return self._w2_split[1]
 
     @staticmethod
-    def _split_scaled(w: torch.Tensor, target: float):
+    def _split_scaled(w: torch.Tensor, target: float, max_shift: Optional[torch.Tensor] = None):
         """(hi, lo, 2^-s): w 2^s with its largest entry in [target, 2 target) per agent, split into float16
         hi + lo (the scaling keeps lo in the float16 normal range; powers of two cancel exactly)."""
         amax = w.abs().amax(dim=tuple(range(1, w.dim()))).clamp_min(1e-30)
         shift = torch.floor(torch.log2(target / amax)).clamp(-14, 14)
+        if max_shift is not None:
+            shift = torch.minimum(shift, max_shift)
         ws = w.float() * torch.exp2(shift).reshape(-1, *([1] * (w.dim() - 1)))
         hi = ws.to(torch.float16)
         return hi, (ws - hi.float()).to(torch.float16), torch.exp2(-shift).float()
@@ -133,7 +135,9 @@ class BatchedPolicy:
             op1 = torch.zeros(V, F1, 16, dtype=torch.float64, device=dev)
             op1[:, :, :IN + 1] = (wc[:, :IN + 1] * self.ln1_w.double()).transpose(1, 2)
             op1[:, :, IN + 1] = self.ln1_b.double()[:, 0]
-            h1, l1, u1 = self._split_scaled(op1.float(), 16.0)
+            # the scaled LayerNorm-1 output (<= sqrt(F1) |ln1_w| + |ln1_b|) must stay inside float16
+            bound = math.sqrt(F1) * self.ln1_w.abs().amax(dim=(1, 2)) + self.ln1_b.abs().amax(dim=(1, 2))
+            h1, l1, u1 = self._split_scaled(op1.float(), 16.0, torch.floor(torch.log2(3.0e4 / bound.clamp_min(1e-30))))
             # (v, t, g, r, h, j) -> (v, g, t, h, r, j): lane = 32 h + r
             w1f = torch.stack([h1, l1], 1).reshape(V, 2, F1 // 32, 32, 2, 8).permute(0, 2, 1, 4, 3, 5).reshape(V, F1 // 32, 2, 64, 8)
             h2, l2, u2 = self._split_scaled(self.W2, 64.0)

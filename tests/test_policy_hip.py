@@ -223,6 +223,15 @@ def test_fused_mlp_edges_and_weight_updates():
         a2, b2 = pol.forward_heads(obs), pol.forward_heads_torch(obs)
         assert not torch.equal(a, a2)
         assert float(((a2 - b2).abs() / b2.abs().amax(dim=-1, keepdim=True).clamp_min(1e-3)).max()) < 2e-5
+    # nearly constant fc1 (tiny weights): the scaling of the fc1 operand is capped so that the scaled LayerNorm-1
+    # output stays inside float16
+    pol = BatchedPolicy(4, 5, 512, 256, device=DEV, seed=3)
+    with torch.no_grad():
+        pol.W1.mul_(1e-3); pol.b1.mul_(1e-3); pol.Wh.mul_(50.0); pol.ln1_w.fill_(3.0); pol.ln1_b.fill_(-0.5)
+    obs = torch.rand(300, 4, 5, device=DEV)
+    a, b = pol.forward_heads(obs), pol.forward_heads_torch(obs)
+    assert torch.isfinite(a).all()
+    assert float(((a - b).abs() / b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-3)).max()) < 5e-5    # rstd ~ 300 amplifies input rounding
     E, V = 32768, 8
     pol = BatchedPolicy(V, 5, 512, 256, device=DEV, seed=1)
     ref = BatchedPolicy(V, 5, 512, 256, device=DEV, seed=1, gemm="fp32")

@@ -30,7 +30,8 @@ grouper = NomaGrouper(env) if V <= 16 else None
 replay = VecReplayBuffer(3 * E, 5, V + 2, V, device="cuda:0")
 power_raw = torch.from_numpy(rng.uniform(-1, 1, (E, V, 2)).astype(np.float32)).cuda()
 probs = torch.from_numpy(rng.dirichlet(np.ones(V), (E, V)).astype(np.float32)).cuda()
-policy = BatchedPolicy(V, 5, 512, 256, device="cuda:0")
+policy = BatchedPolicy(V, 5, 512, 256, device="cuda:0")                       # k_policy_mlp (one launch) where built for the shape
+policy3 = BatchedPolicy(V, 5, 512, 256, device="cuda:0", gemm="fp16x3")       # the three-launch form
 meter = EpisodeMeter(env)
 for _ in range(reps):
     env.make_new_game()
@@ -60,7 +61,8 @@ for _ in range(reps):
     obs = env.tensors["obs"]
     replay.store_batch(obs, a_store, env.tensors["metrics"], env.tensors["reward"], obs, False, mask)   # k_replay_store
     replay.sample_buffer(4096)                                         # k_replay_sample
-    policy.choose_action(obs, mask, cpu_share_floor=0.1)               # k_policy_layer1 + GEMM + k_policy_heads + k_policy_sample
+    policy.choose_action(obs, mask, cpu_share_floor=0.1)               # k_policy_mlp + k_policy_sample
+    policy3.forward_heads(obs)                                         # k_policy_layer1 (split fp16) + fp16 GEMM + k_policy_heads
     meter.begin_episode()                                              # k_episode_clear
     meter.accumulate(env)                                              # k_episode_accumulate
     meter.summarize()                                                  # k_episode_summary + k_episode_fold
@@ -80,7 +82,8 @@ B = dict(
     k_noma_mask=E * (4 * V + V * V + 8), k_noma_group=E * (8 * V + 4 * V * V * 2 + V * V + 16 * V + 40),
     k_noma_flush=E * (8 * V * V + 8 * V + 4),
     # batched policy (5-512-256): layer1 writes h1, heads reads the fc2 product; sample: heads + mask in, all outputs out
-    k_policy_layer1=E * V * (20 + 4 * 512), k_policy_heads=E * V * (4 * 256 + 4 * (4 + V)),
+    k_policy_layer1=E * V * (20 + 3 * 2 * 512), k_policy_heads=E * V * (4 * 256 + 4 * (4 + V)),
+    k_policy_mlp=E * V * (20 + 4 * (4 + V)),          # HBM bytes; the kernel is matrix-core bound (see "flops" in kernel_table)
     k_policy_sample=E * V * (4 * (4 + V) + V + 8 + 4 * V + 4 * V + 12 + 4 * (V + 2)),
     # f4 episode meter: float64 accumulators read + written, the step's metrics / reward / power_w read
     k_episode_clear=E * 8 * (17 + V), k_episode_accumulate=E * (16 * (17 + V) + 56 + 12 * V),
