@@ -4,11 +4,11 @@
 // (the three-launch form moves 805 + 805 + 268 + 268 MB per step at E = 32 768; this one reads the
 // observations and writes the heads).
 //
-// Orientation.  D = A.B with A = fc2 weight (rows = the 32*MT output features), B = hidden layer
-// (columns = 32*NT envs of this wavefront), so after the K loop a LANE holds, for its env (lane & 31),
-// half of that env's output features in registers (C/D map of v_mfma_f32_32x32x16: col = lane & 31,
-// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); the other half sits in lane ^ 32.  LayerNorm over
-// the features and the head GEMV are therefore in-register sums plus ONE cross-lane exchange.
+// Orientation.  D = A.B with A = weights (rows = output features), B = activations (columns = the 32 envs of
+// this wavefront), so after the K loop a LANE holds, for its env (lane & 31), half of that env's output
+// features in registers (C/D map of v_mfma_f32_32x32x16: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) +
+// 4 (lane >> 5)); the other half sits in lane ^ 32.  LayerNorm over the features is therefore in-register sums
+// plus ONE cross-lane exchange, and each layer's output is the next MFMA's B operand as it stands.
 //
 // B operand, generated on the fly -- by the matrix cores too.  LayerNorm needs the row statistics of the fc1
 // pre-activation first; fc1 being linear they have a closed form: with the weight centred over the feature
@@ -27,15 +27,14 @@
 // is multiplied back (exactly) when the fc2 bias is added.  The low part of a small activation (< 0.125) can be
 // a float16 subnormal: absolute error <= 2^-25 per such product, below the float32 rounding of the sum.
 //
-// A operand.  The split weight is stored in FRAGMENT order [chunk][hi|lo][m][lane][8 halfs], so a chunk is
-// 2*MT KiB of contiguous memory that goes global -> LDS by LDS-direct loads (no registers) into the buffer
-// the MFMAs of the current chunk are not reading, and every wavefront reads it back conflict-free.
+// A operand.  The split fc2 weight is stored in FRAGMENT order (per group of 32 hidden features: the fc1 operand
+// of the next group, then two chunks [hi|lo][m][lane][8 halfs]), one contiguous stream per agent that goes
+// L2 -> LDS by LDS-direct loads (no registers) into a ring of three group slots, two groups ahead of the MFMAs:
+// a group's MFMAs are shorter than an L2 round trip.  Counted s_waitcnt vmcnt + raw s_barrier keep the newest
+// group in flight across the barrier.  Every wavefront reads its A fragments back conflict-free (lane-linear).
 //
-// One wavefront per SIMD (256 accumulator registers per lane), so latency is hidden INSIDE the wavefront:
-// the B fragments of chunk c+1 are computed while the MFMAs of chunk c run (the group barriers lay the two
-// independent instruction streams out interleaved).
-#include <cstdlib>
-
+// Workgroup = 8 wavefronts (2 per SIMD, 211 registers each incl. 128 accumulators) sharing one weight stream;
+// one workgroup per CU (123 KB of LDS).  The head weight rides in on the ring's free slot during the last group.
 #include "risvec_launch.hpp"
 #include "risvec_step.hpp"
 
