@@ -259,8 +259,8 @@ def main() -> None:
             policy = BatchedPolicy(V, 5, 512, 256, device=device, seed=rank, env_offset=start)
 
             def marshal():                 # policy forward + sample + marshal; outputs land in the bound tensors
-                out = policy.choose_action(env.tensors["obs"], grouper.mask, cpu_share_floor=floor, want_onehot=False)
-                action.copy_(out[3]); p_off01.copy_(out[4]); a_store.copy_(out[5])
+                policy.choose_action(env.tensors["obs"], grouper.mask, cpu_share_floor=floor, want_onehot=False,
+                                     out=(action, p_off01, a_store))
         marshal()
         replay = VecReplayBuffer(16 * E, 5, V + 2, V, device=device)
         store = replay.bind_store(None, a_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"],

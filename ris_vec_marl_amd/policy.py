@@ -207,13 +207,16 @@ class BatchedPolicy:
 
     def choose_action(self, obs: torch.Tensor, mask: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None,
                       expo: Optional[torch.Tensor] = None, cpu_share_floor: Optional[float] = None,
-                      want_onehot: bool = True) -> Tuple[torch.Tensor, ...]:
+                      want_onehot: bool = True, out: Optional[Sequence[torch.Tensor]] = None) -> Tuple[torch.Tensor, ...]:
         """`agents[i].choose_action(obs_i, mask=mask[i])` for every env and agent (SAC:187-225).
         obs [E,V,5]; mask [E,V,V] uint8/bool (the NOMA mask: row v = who agent v may pick) or None.
         Returns (power_action [E,V,2], intent_probs [E,V,V], intent_onehot [E,V,V] or None); with
         `cpu_share_floor` given, additionally the marshalled (action_env [E,2,V], p_off01 [E,V],
         action_store [E,V*(V+2)]) exactly as `marshal_actions` would produce them -- same launch.
-        `eps` [E,V,2] / `expo` [E,V,V] inject the N(0,1) / Exp(1) draws (parity); default Philox."""
+        `eps` [E,V,2] / `expo` [E,V,V] inject the N(0,1) / Exp(1) draws (parity); default Philox.
+        `out` = (action_env, p_off01, action_store): write the marshalled outputs into these
+        caller-owned contiguous float32 tensors (the ones bound to the env step / NOMA grouping /
+        replay store launchers) instead of new ones."""
         E, V = int(obs.shape[0]), self.n_agents
         if tuple(obs.shape) != (E, V, self.input_dims):
             raise ValueError("obs must have shape [E, %d, %d]" % (V, self.input_dims))
@@ -230,9 +233,17 @@ class BatchedPolicy:
         probs = torch.empty(E, V, V, device=dev)
         onehot = torch.empty(E, V, V, device=dev) if want_onehot else None
         marsh = cpu_share_floor is not None
-        a_env = torch.empty(E, 2, V, device=dev) if marsh else None
-        p01 = torch.empty(E, V, device=dev) if marsh else None
-        a_store = torch.empty(E, V * (V + 2), device=dev) if marsh else None
+        if out is not None:
+            if not marsh:
+                raise ValueError("choose_action: out= needs cpu_share_floor (the marshalled outputs)")
+            a_env, p01, a_store = out
+            for t, shape in ((a_env, (E, 2, V)), (p01, (E, V)), (a_store, (E, V * (V + 2)))):
+                if t.dtype != torch.float32 or t.device != dev or not t.is_contiguous() or tuple(t.shape) != shape:
+                    raise ValueError("choose_action: out tensors must be contiguous float32 [E,2,V], [E,V], [E,V*(V+2)] on %s" % dev)
+        else:
+            a_env = torch.empty(E, 2, V, device=dev) if marsh else None
+            p01 = torch.empty(E, V, device=dev) if marsh else None
+            a_store = torch.empty(E, V * (V + 2), device=dev) if marsh else None
         self._calls += 1
         N.check(N.load().risvec_policy_sample(
             E, V, self.env_offset, heads.data_ptr(), _ptr(mk), self.tau.data_ptr(), self.gumbel_hard.data_ptr(), _ptr(ep),

@@ -66,6 +66,12 @@ def test_vs_golden(path, gemm):
             np.testing.assert_allclose(probs.cpu().numpy()[:, a], d["probs"][a], atol=2e-5)
     m_env, m_p01, m_store = marshal_actions(power, probs, 0.1)               # fused marshalling == separate launch
     assert torch.equal(a_env, m_env) and torch.equal(p01, m_p01) and torch.equal(a_store, m_store)
+    mine = (torch.empty_like(a_env), torch.empty_like(p01), torch.empty_like(a_store))     # caller-owned outputs
+    pol._calls -= 1
+    got = pol.choose_action(T(obs), T(mask), T(eps), T(expo), cpu_share_floor=0.1, out=mine)
+    assert got[3] is mine[0] and all(torch.equal(x, y) for x, y in zip(mine, (a_env, p01, a_store)))
+    with pytest.raises(ValueError):
+        pol.choose_action(T(obs), T(mask), T(eps), T(expo), cpu_share_floor=0.1, out=(mine[0], mine[1], mine[2].double()))
 
 
 @pytest.mark.parametrize("shape", [(8, 512, 256, 1024), (5, 64, 32, 300), (16, 128, 64, 300), (11, 32, 32, 200), (1, 16, 8, 50)])
