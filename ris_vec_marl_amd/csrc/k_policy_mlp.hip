@@ -70,16 +70,15 @@ __device__ __forceinline__ void split16(const f32x8_t& y, half8_t& hi, half8_t& 
     lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x8_t), half8_t);
 }
 
-constexpr int kMlpBlock = 256;       // 8 wavefronts = 2 per SIMD sharing one weight stream
-constexpr int kRing = 2;
-constexpr int kPadRows = 4;             // group slots in LDS: one being read, two in flight / landed
+constexpr int kMlpBlock = 512;       // 8 wavefronts = 2 per SIMD sharing one weight stream
+constexpr int kRing = 3;             // group slots in LDS: one being read, two in flight / landed
 
 template <int MT>
 __global__ void __launch_bounds__(kMlpBlock, 2)
 k_policy_mlp(MlpArgs A) {
     constexpr int F2 = 32 * MT;
     constexpr int kChunkVec = 2 * MT * kWave;                 // uint4 per chunk of 16 hidden features
-    constexpr int kGroupVec = kPadRows * kWave + 2 * kChunkVec;      // uint4 per group of 32: fc1 operand of the NEXT group (2 of 8 KiB used), 2 chunks
+    constexpr int kGroupVec = 8 * kWave + 2 * kChunkVec;      // uint4 per group of 32: fc1 operand of the NEXT group (2 of 8 KiB used), 2 chunks
     constexpr int kStage = kGroupVec / kMlpBlock;             // LDS-direct loads per wavefront per group
     static_assert(kGroupVec % kMlpBlock == 0, "group must split evenly over the workgroup");
     extern __shared__ uint4 s_raw[];
@@ -179,23 +178,26 @@ k_policy_mlp(MlpArgs A) {
     uint4* s_heads = s_ring + (NG % kRing) * kGroupVec;       // free from the last group on
     f32x16_t d = layer1(s_ring + (kRing - 1) * kGroupVec);
     stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NG > 1) stage(1);
+    if (NG > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStage) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     half8_t b0[2], b1[2];
     for (int g = 0; g < NG; ++g) {
         const uint4* slot = s_ring + (g % kRing) * kGroupVec;
         make_b(d, 0, b0);
-        if (g + 1 < NG) {
-            stage(g + 1);
-        } else {                             // last group: the head weight rides in on the free slot
+        if (g + 2 < NG) {
+            stage(g + 2);
+        } else if (g + 1 == NG) {                             // last group: the head weight rides in on the free slot
             for (int i = tid; i < 4 * MT * kWave; i += kMlpBlock)
                 __builtin_amdgcn_global_load_lds((const gvoid_t*)(hsrc + i), (lvoid_t*)(s_heads + i), 16, 0, 0);
         }
-        mfma_chunk(slot + kPadRows * kWave, b0);
+        mfma_chunk(slot + 8 * kWave, b0);
         make_b(d, 1, b1);                                     // beside chunk 0's MFMAs
         if (g + 1 < NG) d = layer1(slot);                     // the next group's fc1 product: its operand came with this slot
-        mfma_chunk(slot + kPadRows * kWave + kChunkVec, b1);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        mfma_chunk(slot + 8 * kWave + kChunkVec, b1);
+        if (g + 2 < NG) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kStage) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 
@@ -282,7 +284,7 @@ k_policy_mlp(MlpArgs A) {
 template <int MT>
 hipError_t launch_mlp(const MlpArgs& a, hipStream_t st) {
     const int F2 = 32 * MT;
-    const size_t lds = (size_t)kRing * (kPadRows * kWave + 4 * MT * kWave) * sizeof(uint4) + ((size_t)3 * F2 + 32 + kIn1 * kIn1) * sizeof(float);
+    const size_t lds = (size_t)kRing * (8 * kWave + 4 * MT * kWave) * sizeof(uint4) + ((size_t)3 * F2 + 32 + kIn1 * kIn1) * sizeof(float);
     auto kern = k_policy_mlp<MT>;
     if (lds > 64 * 1024) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

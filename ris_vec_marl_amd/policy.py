@@ -151,9 +151,9 @@ class BatchedPolicy:
             hfrag = torch.stack([hh, hl], 1).reshape(V, 2, F2 // 32, 2, 2, 2, 4, 32).permute(0, 2, 3, 1, 5, 7, 4, 6).contiguous()
             # the weight stream, per group of 32 hidden features: fc1 operand of the NEXT group (8 KiB slot), two chunks
             MT, NG = F2 // 32, F1 // 32
-            stream = torch.zeros(V, NG, 4 + 4 * MT, 64, 8, dtype=torch.float16, device=dev)
+            stream = torch.zeros(V, NG, 8 + 4 * MT, 64, 8, dtype=torch.float16, device=dev)
             stream[:, :-1, 0:2] = w1f[:, 1:]
-            stream[:, :, 4:] = frag.reshape(V, NG, 4 * MT, 64, 8)
+            stream[:, :, 8:] = frag.reshape(V, NG, 4 * MT, 64, 8)
             self._fused_w = (key, (gram.float().contiguous(), w1f[:, 0].contiguous(), stream, (u1 * u2).contiguous(), hfrag,
                                    uh.contiguous()))
         return self._fused_w[1]
