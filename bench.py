@@ -390,3 +390,8 @@ def main() -> None:
 
 if __name__ == "__main__":
     main()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        try:                                   # every rank gets here right after the timed region
+            torch.distributed.destroy_process_group()
+        except Exception:
+            pass
