@@ -32,26 +32,37 @@ grouper = NomaGrouper(env)
 memory = VecReplayBuffer(8 * N_STEP * E, 5, V + 2, V, device="cuda:0")
 meter, writer = EpisodeMeter(env), ScalarSink(LOG_DIR)           # the driver's ep_* sums and its SummaryWriter
 
+# Tensors every stage reads / writes in place, and one pre-marshalled launcher per stage: inside the step loop
+# the host does nothing but issue launches (the unbound methods -- env.step(...), memory.store_batch(...) --
+# do the same work with the argument checking on every call).
+action_env = torch.zeros(E, 2, V, device="cuda:0")               # env action            (TRAIN:1601-1608)
+p_off01 = torch.zeros(E, V, device="cuda:0")                     # pairing power         (TRAIN:1391-1396)
+action_store = torch.zeros(E, V * (V + 2), device="cuda:0")      # replay action row     (TRAIN:1776-1784)
+env.update_channel_gains()
+grouper.begin_episode(0)
+mask = grouper.refresh_mask()                                    # [E,V,V] uint8, updated in place by later refreshes
+partner, n_groups = grouper.group(p_off01, 0)                    # state views the step launcher can bind
+step = env.bind_step(action_env, partner, n_groups)
+group = grouper.bind_group(p_off01)
+store = memory.bind_store(None, action_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"], mask)
+count = meter.bind(env)
+
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for ep in range(EPISODES):
     env.begin_episode(ep, env_refresh_every=5)
     grouper.begin_episode(ep)
     meter.begin_episode()
-    state_old = env.observe().clone()
-    mask = None
     for st in range(N_STEP):
         refreshed = env.begin_step(st, ris_every=RIS_EVERY)       # BCD sweep + gains on refresh steps
         if refreshed:
-            mask = grouper.refresh_mask()
-        _, _, _, action_env, p_off01, action_store = policy.choose_action(state_old, mask, cpu_share_floor=env.cpu_share_floor,
-                                                                          want_onehot=False)
-        partner, n_groups = grouper.group(p_off01, st)
-        env.step(action_env, partner, n_groups)
-        memory.store_batch(state_old, action_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"],
-                           done=(st == N_STEP - 1), mask=mask if refreshed else None)
-        state_old.copy_(env.tensors["obs"])
-        meter.accumulate(env)
+            grouper.refresh_mask()
+        policy.choose_action(env.tensors["obs"], mask, cpu_share_floor=env.cpu_share_floor, want_onehot=False,
+                             out=(action_env, p_off01, action_store))
+        group(st)
+        step()
+        store(done=(st == N_STEP - 1), use_mask=refreshed)
+        count()
     batch = memory.sample_buffer(256)               # what global_learn would consume
     sc = writer.write_episode(meter, ep)            # the driver's tags, mean over the envs
     print("episode %d: global reward %.3f, delay %.2f ms, energy %.2e J, QoS violations %.1f %%, Jain %.3f, "
