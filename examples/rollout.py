@@ -46,6 +46,7 @@ step = env.bind_step(action_env, partner, n_groups)
 group = grouper.bind_group(p_off01)
 store = memory.bind_store(None, action_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"], mask)
 count = meter.bind(env)
+policy.forward_heads(env.tensors["obs"])                         # untimed: first-launch costs (code objects, weight preparation)
 
 torch.cuda.synchronize()
 t0 = time.perf_counter()
