@@ -160,15 +160,36 @@ k_policy_mlp(MlpArgs A) {
         for (int q = 0; q < kStage; ++q)
             __builtin_amdgcn_global_load_lds((const gvoid_t*)(src + q * kMlpBlock + tid), (lvoid_t*)(dst + q * kMlpBlock + tid), 16, 0, 0);
     };
+    // A fragments are read two feature tiles (six MFMAs) ahead of their use, by hand: hipcc sinks LDS reads next
+    // to their first use and then waits lgkmcnt(0), which exposes the LDS latency in front of every third MFMA.
+    // The reads are inline asm (issued in program order), and each counted wait names the fragments it releases,
+    // so the MFMAs that consume them cannot be moved above it.  Compiler-generated LDS reads may interleave:
+    // counters retire in order, so extra reads can only make either side wait longer, never too little.
     auto mfma_chunk = [&](const uint4* sa, const half8_t (&bf)[2]) {
+        const uint32_t base = (uint32_t)(size_t)(lvoid_t*)(sa + lane);
+        half8_t ah[3], al[3];
+#define RISVEC_RD(M_) do {                                                                                          \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[(M_) % 3]) : "v"(base), "n"((M_) * kWave * 16));          \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[(M_) % 3]) : "v"(base), "n"((MT + (M_)) * kWave * 16));   \
+        } while (0)
+        RISVEC_RD(0);
+        if constexpr (MT > 1) RISVEC_RD(1);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const half8_t ah = __builtin_bit_cast(half8_t, sa[m * kWave + lane]);
-            const half8_t al = __builtin_bit_cast(half8_t, sa[(MT + m) * kWave + lane]);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bf[0], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bf[0], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bf[1], acc[m], 0, 0, 0);
+            if (m + 2 < MT) {
+                if (m == 0) RISVEC_RD(2); else if (m == 1) RISVEC_RD(3); else if (m == 2) RISVEC_RD(4);
+                else if (m == 3) RISVEC_RD(5); else if (m == 4) RISVEC_RD(6); else RISVEC_RD(7);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[m % 3]), "+v"(al[m % 3]));
+            } else if (m + 1 < MT) {
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[m % 3]), "+v"(al[m % 3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[m % 3]), "+v"(al[m % 3]));
+            }
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m % 3], bf[0], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m % 3], bf[0], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m % 3], bf[1], acc[m], 0, 0, 0);
         }
+#undef RISVEC_RD
     };
 
     // The weight stream runs two groups ahead of the MFMAs (a chunk of MFMAs is shorter than an L2 round trip):
