@@ -81,6 +81,8 @@ k_policy_mlp(MlpArgs A) {
     constexpr int kGroupVec = 8 * kWave + 2 * kChunkVec;      // uint4 per group of 32: fc1 operand of the NEXT group (2 of 8 KiB used), 2 chunks
     constexpr int kStage = kGroupVec / kMlpBlock;             // LDS-direct loads per wavefront per group
     static_assert(kGroupVec % kMlpBlock == 0, "group must split evenly over the workgroup");
+    constexpr int kHeadStage = 4 * MT * kWave / kMlpBlock;    // LDS-direct loads per wavefront for the head weight
+    static_assert((4 * MT * kWave) % kMlpBlock == 0, "head weight must split evenly over the workgroup");
     extern __shared__ uint4 s_raw[];
     const int H = A.H, NG = A.F1 / 32;
     uint4* s_ring = s_raw;                                    // [kRing][kGroupVec]
@@ -90,6 +92,26 @@ k_policy_mlp(MlpArgs A) {
 
     const int v = blockIdx.y, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const uint4* wsrc = A.W2f + (size_t)v * NG * kGroupVec;
+    auto stage = [&](int g) {                                 // group g of the weight stream, global -> LDS directly
+        const uint4* src = wsrc + (size_t)g * kGroupVec;
+        uint4* dst = s_ring + (g % kRing) * kGroupVec;
+#pragma unroll
+        for (int q = 0; q < kStage; ++q)
+            __builtin_amdgcn_global_load_lds((const gvoid_t*)(src + q * kMlpBlock + tid), (lvoid_t*)(dst + q * kMlpBlock + tid), 16, 0, 0);
+    };
+    // The first two groups of the weight stream, this lane's observation and the parameter tables are all requested
+    // before anything waits: one L2 round trip in front of the K loop instead of three in a row.
+    stage(0);
+    if (NG > 1) stage(1);
+    const long long row0 = ((long long)blockIdx.x * (kMlpBlock / kWave) + wave) * 32;
+    const long long e = row0 + r;
+    float x[kIn1];
+    {
+        const float* xin = A.obs + ((e < A.E ? e : 0) * A.V + v) * A.IN;
+#pragma unroll
+        for (int i = 0; i < kIn1; ++i) x[i] = i < A.IN ? xin[i < A.IN ? i : 0] : (i == A.IN ? 1.0f : 0.0f);
+    }
     for (int i = tid; i < F2; i += kMlpBlock) {
         s_p2[i] = A.b2[(size_t)v * F2 + i]; s_p2[F2 + i] = A.ln2w[(size_t)v * F2 + i]; s_p2[2 * F2 + i] = A.ln2b[(size_t)v * F2 + i];
     }
@@ -101,14 +123,8 @@ k_policy_mlp(MlpArgs A) {
 
     // this lane's env, its LayerNorm-1 scale, and the B operand of the fc1 product: [x rstd, rstd, 1, 0..] in the
     // k-slots of the low lane half, zeros in the high half
-    const long long row0 = ((long long)blockIdx.x * (kMlpBlock / kWave) + wave) * 32;
-    const long long e = row0 + r;
     half8_t xh, xl;
     {
-        const float* xin = A.obs + ((e < A.E ? e : 0) * A.V + v) * A.IN;
-        float x[kIn1];
-#pragma unroll
-        for (int i = 0; i < kIn1; ++i) x[i] = i < A.IN ? xin[i < A.IN ? i : 0] : (i == A.IN ? 1.0f : 0.0f);
         float var = 0.0f;
 #pragma unroll
         for (int i = 0; i < kIn1; ++i) {
@@ -152,14 +168,6 @@ k_policy_mlp(MlpArgs A) {
         for (int j = 0; j < 8; ++j) y[j] = fmaxf(d[8 * u + j], 0.0f);
         split16(y, bf[0], bf[1]);
     };
-    const uint4* wsrc = A.W2f + (size_t)v * NG * kGroupVec;
-    auto stage = [&](int g) {                                 // group g of the weight stream, global -> LDS directly
-        const uint4* src = wsrc + (size_t)g * kGroupVec;
-        uint4* dst = s_ring + (g % kRing) * kGroupVec;
-#pragma unroll
-        for (int q = 0; q < kStage; ++q)
-            __builtin_amdgcn_global_load_lds((const gvoid_t*)(src + q * kMlpBlock + tid), (lvoid_t*)(dst + q * kMlpBlock + tid), 16, 0, 0);
-    };
     // A fragments are read two feature tiles (six MFMAs) ahead of their use, by hand: hipcc sinks LDS reads next
     // to their first use and then waits lgkmcnt(0), which exposes the LDS latency in front of every third MFMA.
     // The reads are inline asm (issued in program order), and each counted wait names the fragments it releases,
@@ -198,66 +206,70 @@ k_policy_mlp(MlpArgs A) {
     const uint4* hsrc = A.WhF + (size_t)v * (4 * MT * kWave);
     uint4* s_heads = s_ring + (NG % kRing) * kGroupVec;       // free from the last group on
     f32x16_t d = layer1(s_ring + (kRing - 1) * kGroupVec);
-    stage(0);
-    if (NG > 1) stage(1);
-    if (NG > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStage) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // every wavefront has read the group-0 fc1 operand ...
+    __builtin_amdgcn_s_barrier();                                // ... before group 2 is staged over it
     half8_t b0[2], b1[2];
     for (int g = 0; g < NG; ++g) {
         const uint4* slot = s_ring + (g % kRing) * kGroupVec;
         make_b(d, 0, b0);
         if (g + 2 < NG) {
             stage(g + 2);
-        } else if (g + 1 == NG) {                             // last group: the head weight rides in on the free slot
-            for (int i = tid; i < 4 * MT * kWave; i += kMlpBlock)
-                __builtin_amdgcn_global_load_lds((const gvoid_t*)(hsrc + i), (lvoid_t*)(s_heads + i), 16, 0, 0);
+        } else if (g + 2 == NG || NG == 1) {                  // nothing left to stage: the head weight rides in on the
+#pragma unroll                                                //  free slot, one group before it is needed
+            for (int q = 0; q < kHeadStage; ++q)
+                __builtin_amdgcn_global_load_lds((const gvoid_t*)(hsrc + q * kMlpBlock + tid), (lvoid_t*)(s_heads + q * kMlpBlock + tid), 16, 0, 0);
         }
         mfma_chunk(slot + 8 * kWave, b0);
         make_b(d, 1, b1);                                     // beside chunk 0's MFMAs
         if (g + 1 < NG) d = layer1(slot);                     // the next group's fc1 product: its operand came with this slot
         mfma_chunk(slot + 8 * kWave + kChunkVec, b1);
         if (g + 2 < NG) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kStage) : "memory");
+        else if (g + 2 == NG) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kHeadStage) : "memory");   // last group landed
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 
     // ---- fc2 bias + LayerNorm + ReLU, in registers: this lane owns features 32m + (q & 3) + 8 (q >> 2) + 4h of its env
+    // (whole-tile vector arithmetic: the compiler turns it into packed two-lane float32 instructions)
     const float inv_f2 = 1.0f / (float)F2, unscale = A.gscale[v];
     {
-        float s = 0.0f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
+        auto tile_of = [&](const float* tab, int m) {            // 16 per-feature parameters in C/D register order
+            f32x16_t t;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 b = *reinterpret_cast<const float4*>(s_p2 + 32 * m + 8 * g + 4 * h);
-                const float bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    acc[m][4 * g + k] = fmaf(acc[m][4 * g + k], unscale, bb[k]);
-                    s += acc[m][4 * g + k];
-                }
+                const float4 q4 = *reinterpret_cast<const float4*>(tab + 32 * m + 8 * g + 4 * h);
+                t[4 * g] = q4.x; t[4 * g + 1] = q4.y; t[4 * g + 2] = q4.z; t[4 * g + 3] = q4.w;
             }
+            return t;
+        };
+        f32x16_t vs;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = acc[m] * unscale + tile_of(s_p2, m);
+            vs = m == 0 ? acc[0] : vs + acc[m];
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += vs[q];
         s += __shfl_xor(s, 32, kWave);
         const float mean = s * inv_f2;
+        f32x16_t v2;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = acc[m] - mean;                               // centred once, reused by the normalisation
+            v2 = m == 0 ? acc[0] * acc[0] : v2 + acc[m] * acc[m];
+        }
         float s2 = 0.0f;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { const float dd = acc[m][q] - mean; s2 = fmaf(dd, dd, s2); }
+        for (int q = 0; q < 16; ++q) s2 += v2[q];
         s2 += __shfl_xor(s2, 32, kWave);
         const float rs = rsqrtf(s2 * inv_f2 + kLnEps);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = (acc[m] * rs) * tile_of(s_p2 + F2, m) + tile_of(s_p2 + 2 * F2, m);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 w = *reinterpret_cast<const float4*>(s_p2 + F2 + 32 * m + 8 * g + 4 * h);
-                const float4 b = *reinterpret_cast<const float4*>(s_p2 + 2 * F2 + 32 * m + 8 * g + 4 * h);
-                const float ww[4] = {w.x, w.y, w.z, w.w}, bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    acc[m][4 * g + k] = fmaxf(fmaf((acc[m][4 * g + k] - mean) * rs, ww[k], bb[k]), 0.0f);
-            }
+            for (int q = 0; q < 16; ++q) acc[m][q] = fmaxf(acc[m][q], 0.0f);
+        }
     }
 
     // ---- heads on the matrix cores: D[head][env] = Wh^T . y with the accumulator registers themselves as the B
