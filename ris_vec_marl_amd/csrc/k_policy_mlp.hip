@@ -33,7 +33,7 @@
 // a group's MFMAs are shorter than an L2 round trip.  Counted s_waitcnt vmcnt + raw s_barrier keep the newest
 // group in flight across the barrier.  Every wavefront reads its A fragments back conflict-free (lane-linear).
 //
-// Workgroup = 8 wavefronts (2 per SIMD, 211 registers each incl. 128 accumulators) sharing one weight stream;
+// Workgroup = 8 wavefronts (2 per SIMD, 220 registers each incl. 128 accumulators) sharing one weight stream;
 // one workgroup per CU (123 KB of LDS).  The head weight rides in on the ring's free slot during the last group.
 #include "risvec_launch.hpp"
 #include "risvec_step.hpp"
