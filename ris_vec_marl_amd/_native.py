@@ -203,6 +203,18 @@ def _sizeof_check(lib) -> int:
     return int(p.struct_bytes)
 
 
+def resolve_device(device):
+    """`torch.device(device)` with the index of a bare "cuda" filled in (the current device), so that
+    `tensor.device == self.device` holds for tensors the object allocates itself: torch compares
+    `cuda` and `cuda:0` as different devices.  Without a HIP device the argument is returned as
+    given (the compute calls raise later: there is no CPU fallback)."""
+    import torch
+    d = torch.device(device if device is not None else "cuda")
+    if d.type == "cuda" and d.index is None and torch.cuda.is_available():
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 class RisVecError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__("librisvec error %d: %s" % (code, msg))

@@ -55,38 +55,57 @@ class JointObsGather:
     critical path, and nothing it reads or writes is touched by them.  `wait()` makes the
     result visible to the caller's stream.  xGMI is point-to-point, so the gather is per-link
     bound ((N-1) x message bytes into every GPU): pick its cadence accordingly.  Equal shard
-    sizes are required (use an E divisible by the world size)."""
+    sizes are required (use an E divisible by the world size).
+
+    A single process (no process group, or a group of one rank) runs the SAME staging / side-stream
+    / double-buffer sequence with the collective replaced by a device copy (a one-rank group still
+    issues the collective), so the single-GPU tests exercise the logic the multi-GPU run relies on."""
 
     def __init__(self, n_envs_local: int, n_veh: int, device, group=None, n_buffers: int = 2):
         self.group = group
-        self.world = td.get_world_size(group) if td.is_initialized() else 1
+        self.collective = td.is_available() and td.is_initialized()
+        self.world = td.get_world_size(group) if self.collective else 1
+        self.backend = td.get_backend(group) if self.collective else "none"
         self.device = torch.device(device)
-        self.width = 5 * n_veh
-        self.stage = torch.empty(n_envs_local, self.width, dtype=torch.float32, device=self.device)
-        self.bufs = [torch.empty(self.world * n_envs_local, self.width, dtype=torch.float32, device=self.device)
+        if self.collective and self.backend == "nccl" and self.device.type != "cuda":
+            raise ValueError("JointObsGather: the nccl (RCCL) backend needs a cuda device, got %s" % self.device)
+        if n_buffers < 1:
+            raise ValueError("JointObsGather: n_buffers must be >= 1")
+        self.n_envs_local = int(n_envs_local)
+        self.width = 5 * int(n_veh)
+        self.stage = torch.empty(self.n_envs_local, self.width, dtype=torch.float32, device=self.device)
+        self.bufs = [torch.empty(self.world * self.n_envs_local, self.width, dtype=torch.float32, device=self.device)
                      for _ in range(n_buffers)]
         self.i = 0
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._work = None
+        self.n_started = 0
 
     def start(self, obs_local: torch.Tensor) -> torch.Tensor:
         """Snapshot `obs_local` and launch its gather; returns the buffer it will land in
         (valid after `wait()`)."""
+        if obs_local.shape[0] != self.n_envs_local or obs_local.numel() != self.n_envs_local * self.width:
+            raise ValueError("JointObsGather.start: obs_local must be [%d, V, 5] with 5V = %d, got %s"
+                             % (self.n_envs_local, self.width, tuple(obs_local.shape)))
         self.wait()                                   # the previous gather still reads `stage`
         out = self.bufs[self.i]
         self.i = (self.i + 1) % len(self.bufs)
-        src = obs_local.reshape(obs_local.shape[0], self.width)
-        if self.world == 1:
-            out.copy_(src, non_blocking=True)
-            return out
-        self.stage.copy_(src, non_blocking=True)
+        self.n_started += 1
+        src = obs_local.reshape(self.n_envs_local, self.width)
+        self.stage.copy_(src, non_blocking=True)      # caller's stream: ordered after the step that wrote obs
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.stream):
-                self._work = td.all_gather_into_tensor(out, self.stage, group=self.group, async_op=True)
+                self._issue(out)
         else:
-            self._work = td.all_gather_into_tensor(out, self.stage, group=self.group, async_op=True)
+            self._issue(out)
         return out
+
+    def _issue(self, out: torch.Tensor) -> None:
+        if self.collective:
+            self._work = td.all_gather_into_tensor(out, self.stage, group=self.group, async_op=True)
+        else:
+            out.copy_(self.stage, non_blocking=True)
 
     def wait(self) -> None:
         """Make the last started gather visible to the current stream."""

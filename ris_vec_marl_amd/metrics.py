@@ -54,7 +54,7 @@ class EpisodeMeter:
         N.load()
         if env is not None:
             n_envs, n_veh, device = env.n_envs, env.n_veh, env.device
-        self.device = torch.device(device if device is not None else "cuda")
+        self.device = N.resolve_device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ris_vec_marl_amd needs a HIP device; there is no CPU fallback")
         self.n_envs, self.n_veh, self.user_clip = int(n_envs), int(n_veh), float(user_clip)

@@ -46,7 +46,7 @@ class BatchedPolicy:
         N.load()
         if n_actions != 2:
             raise ValueError("the reference's power head has 2 outputs (offload, local); got %d" % n_actions)
-        self.device = torch.device(device)
+        self.device = N.resolve_device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ris_vec_marl_amd needs a HIP device; there is no CPU fallback")
         self.n_agents, self.input_dims, self.fc1_dims, self.fc2_dims = int(n_agents), int(input_dims), int(fc1_dims), int(fc2_dims)

@@ -28,7 +28,7 @@ class VecReplayBuffer:
 
     def __init__(self, max_size: int, input_shape: int, n_actions: int, n_agents: int, device="cuda", seed: int = 0):
         N.load()
-        self.device = torch.device(device)
+        self.device = N.resolve_device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ris_vec_marl_amd needs a HIP device; there is no CPU fallback")
         self.mem_size = int(max_size)

@@ -71,7 +71,7 @@ class VecEnviron(ParamAttrs):
         self.n_envs = int(n_envs)
         self.env_offset = int(env_offset)
         self.seed = int(seed)
-        self.device = torch.device(device)
+        self.device = N.resolve_device(device)
         if not 1 <= self.n_veh <= N.MAX_VEH:
             raise ValueError("n_veh must be in [1, %d]" % N.MAX_VEH)
         if self.n_envs < 1 or self.M < 1:
@@ -89,6 +89,7 @@ class VecEnviron(ParamAttrs):
         self._moves = 0          # renew_positions counter
         self._steps = 0          # step counter    (RNG counter for arrivals)
         self._chan = 0           # 3GPP-gain / random-phase counter
+        self._obs_stale = True   # obs[E,V,5] does not reflect the state tensors (no step since the last reset)
         self._t: Dict[str, torch.Tensor] = {}
         self._colsum_valid = False     # c_col matches h_r (set by compute_parms / rebuild_colsum)
         self._steer_valid = False      # h_r is the steering vector compute_parms wrote, z_r its base
@@ -108,6 +109,7 @@ class VecEnviron(ParamAttrs):
             return
         lib = N.load()       # raises if the extension is not built
         del lib
+        self.device = N.resolve_device(self.device)      # a bare "cuda" becomes cuda:<current>
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ris_vec_marl_amd needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -179,6 +181,16 @@ class VecEnviron(ParamAttrs):
             raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(tt.shape)))
         return tt.to(device=self.device, dtype=dtype).contiguous()
 
+    def _bound(self, x, dtype, shape, name) -> Optional[torch.Tensor]:
+        """An input of a pre-marshalled launcher: used as is or refused, never copied."""
+        if x is None:
+            return None
+        if (not isinstance(x, torch.Tensor) or x.dtype != dtype or x.device != self.device or not x.is_contiguous()
+                or tuple(x.shape) != tuple(shape)):
+            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s (bound launchers read their inputs "
+                             "in place; convert it once before binding)" % (name, dtype, tuple(shape), self.device))
+        return x
+
     # ------------------------------------------------------------------ tensors (views)
     @property
     def tensors(self) -> Dict[str, torch.Tensor]:
@@ -212,6 +224,7 @@ class VecEnviron(ParamAttrs):
         self._epoch += 1
         N.check(N.load().risvec_reset(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(si), _dev_ptr(b0),
                                       self.seed, self._epoch, self._stream()))
+        self._obs_stale = True         # DataBuf changed under the observation the last step wrote
 
     def renew_positions(self, u_turn=None, return_n_used: bool = False):
         """Environment.py:412-542.  u_turn [E,V,8] float32 injected uniform draws."""
@@ -367,6 +380,7 @@ class VecEnviron(ParamAttrs):
         if bcd:
             self._bcd_done(flags, step=True)
         self._steps += 1
+        self._obs_stale = not obs
         t = self._t
         return (t["reward"], t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"],
                 t["over_data"])
@@ -390,6 +404,7 @@ class VecEnviron(ParamAttrs):
         if ph is not None:
             self._ssum_sweeps = 0
         self._steps += 1
+        self._obs_stale = False        # sarl_observe assembles its own observation from the state tensors
         t = self._t
         return (t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"], t["over_data"])
 
@@ -403,10 +418,12 @@ class VecEnviron(ParamAttrs):
         batched step is only a few microseconds of GPU time (small E)."""
         self._ensure_device()
         E, V = self.n_envs, self.n_veh
-        a = self._arg(action_power, torch.float32, (E, V, 2) if policy_action else (E, 2, V), "action_power")
-        pt = self._arg(partner, torch.int32, (E, V), "partner")
-        ng = self._arg(n_groups, torch.int32, (E,), "n_groups")
-        ar = self._arg(arrivals, torch.int32, (E, V), "arrivals")
+        # the launcher reads these tensors IN PLACE on every call, so they must already be what the
+        # kernel reads: a silent .to()/.contiguous() copy would detach the caller's later updates
+        a = self._bound(action_power, torch.float32, (E, V, 2) if policy_action else (E, 2, V), "action_power")
+        pt = self._bound(partner, torch.int32, (E, V), "partner")
+        ng = self._bound(n_groups, torch.int32, (E,), "n_groups")
+        ar = self._bound(arrivals, torch.int32, (E, V), "arrivals")
         base_flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
                       | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0)
                       | self._steer_flag(steer, fused or bcd))
@@ -424,6 +441,7 @@ class VecEnviron(ParamAttrs):
             if bcd:
                 self._bcd_done(flags, step=True)
             self._steps += 1
+            self._obs_stale = not obs
 
         launch.inputs = keep
         return launch
@@ -433,10 +451,16 @@ class VecEnviron(ParamAttrs):
         """marl_train_bcd.py:819-827 for all agents: [E,V,5].  After a step the kernel has
         already written it; before the first step it is assembled from the state."""
         t = self.tensors
-        if self._steps == 0:
+        if self._obs_stale:
+            # what marl_get_state reads at this point: the CURRENT attributes (a reset replaces DataBuf
+            # and leaves data_t / data_p / vehicle_rate of the last step alone, Environment.py:733-737)
             o = t["obs"]
-            o.zero_()
             o[..., 0] = t["data_buf"] / 10
+            o[..., 1] = t["data_t"] / 10
+            o[..., 2] = t["data_p"] / 10
+            o[..., 3] = 0
+            o[..., 4] = t["rate"] / 20
+            self._obs_stale = False
         return t["obs"]
 
     def metrics_dict(self) -> Dict[str, torch.Tensor]:
@@ -462,24 +486,35 @@ class VecEnviron(ParamAttrs):
 
     # ------------------------------------------------------------------ checkpoint
     _STATE_KEYS = ("pos", "dir", "vel", "dist_r", "ang_r", "pl", "h_r", "z_r", "theta", "gain", "data_buf", "mec_q",
-                   "rate", "data_t", "data_p", "reward", "over_power", "over_data", "obs", "metrics")
+                   "rate", "data_t", "data_p", "reward", "over_power", "over_data", "obs", "metrics", "power_w")
 
     def state_dict(self) -> Dict[str, object]:
         t = self.tensors
         sd: Dict[str, object] = {k: t[k].detach().cpu().clone() for k in self._STATE_KEYS}
         sd["counters"] = dict(epoch=self._epoch, moves=self._moves, steps=self._steps, chan=self._chan,
-                              seed=self.seed, env_offset=self.env_offset, steer_valid=self._steer_valid)
+                              seed=self.seed, env_offset=self.env_offset, steer_valid=self._steer_valid,
+                              obs_stale=self._obs_stale)
         return sd
 
     def load_state_dict(self, sd: Dict[str, object]) -> None:
+        """Restore a `state_dict()`.  The Philox streams are keyed by (seed, global env id), so a
+        checkpoint only resumes bit-identically in an env built with the SAME seed and env_offset:
+        a mismatch raises instead of silently diverging."""
+        c = sd["counters"]
+        for key, mine in (("seed", self.seed), ("env_offset", self.env_offset)):
+            if key in c and int(c[key]) != int(mine):
+                raise ValueError("load_state_dict: checkpoint was taken with %s=%d, this env has %s=%d (the RNG "
+                                 "streams are keyed by it; build the env with the checkpoint's value)"
+                                 % (key, int(c[key]), key, int(mine)))
         t = self.tensors
         for k in self._STATE_KEYS:
-            t[k].copy_(sd[k])
+            if k in sd:                # power_w joined the checkpoint in round 2
+                t[k].copy_(sd[k])
         self._colsum_valid = False
         self._ssum_sweeps = 0
-        c = sd["counters"]
         self._epoch, self._moves, self._steps, self._chan = c["epoch"], c["moves"], c["steps"], c["chan"]
         self._steer_valid = bool(c.get("steer_valid", False))      # z_r travels with h_r
+        self._obs_stale = bool(c.get("obs_stale", self._steps == 0))
 
 
 # reference attribute name -> tensor key

@@ -90,3 +90,59 @@ def test_single_process_gather_is_a_copy():
     assert y.shape == (2, 15) and torch.equal(y, x.reshape(2, 15))
     s3 = torch.arange(63, dtype=torch.float64).reshape(3, 21)
     assert torch.equal(rdist.combine_episode_summary(s3, 5), s3)
+
+
+# ---------------------------------------------------------------------------- bench.py's own launcher
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env=None, timeout=300):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), cwd=ROOT, env=e,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launcher_spawns_the_ranks_it_was_asked_for():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start 2 rank processes itself (here: gloo on CPU with
+    the HIP step stubbed out -- what is under test is the launcher, the rendezvous, the sharding, the gather
+    cadence and the max-over-ranks timing), and rank 0 prints the one JSON line."""
+    import json
+    r = _bench("--gpus", "2", "--stub", "--steps", "5", "--warmup", "2", "--envs-per-gpu", "16", "--gather-every", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["stub"] is True and d["value"] is None          # a self-test line can never be mistaken for a measurement
+    assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["gather_ok"] is True
+    assert abs(d["max_over_ranks_s"] - 0.002) < 1e-12          # MAX over ranks (rank 1 reported 2 ms)
+
+
+def test_bench_never_silently_runs_fewer_ranks():
+    """No device in this container: `--gpus 2` must exit non-zero (not fall back to one rank), and a WORLD_SIZE that
+    differs from --gpus is refused as well."""
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert r.returncode != 0 and "refusing" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = _bench("--gpus", "4", "--stub", "--steps", "1", "--warmup", "0",
+               env=dict(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_workload_labels():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("risvec_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.workload_name(4096, 8, 36, "fused", 1) == "BASELINE configs[1]"
+    assert b.workload_name(32768, 8, 64, "fused", 1) == "BASELINE configs[2]"
+    assert b.workload_name(8192, 8, 64, "fused", 8) == "BASELINE configs[3]"
+    assert "shard" in b.workload_name(8192, 8, 64, "fused", 1)
+    assert b.workload_name(32768, 16, 256, "bcd", 1) == "BASELINE configs[4]"
+    assert "custom" in b.workload_name(1000, 8, 64, "fused", 1)
+    assert b.algorithmic_bytes(8, 64) == 5188 and b.algorithmic_bytes(8, 36) == 3172 and b.algorithmic_bytes(16, 256, "bcd") == 37956
+    assert b.usable_cores() >= 1

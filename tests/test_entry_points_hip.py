@@ -1,0 +1,285 @@
+"""GPU tests of the entry points the BASELINE configs are actually benchmarked through
+(round 2): `step(bcd=True)` / `bind_step(bcd=True)` -> `risvec_step_fused_bcd` (config 5), the
+on-device joint-observation gather (config 4) and the objects built with the DEFAULT device.
+Everything goes through the C ABI; the oracle is the checker."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import risvec_oracle as orc  # noqa: E402  (checker)
+from tests.test_hip_parity import (RT, c128, check_step, cpu, make_vec, put_complex, random_step_inputs, snap,  # noqa: E402
+                                   step_mask)
+
+
+# ---------------------------------------------------------------------------- config 5 entry point
+def _bcd_step_reference(t, th_in, B0, Q0, action, partner, ng, arrivals, p, bbit):
+    """oracle for ONE step(bcd=True): bcd_sweep -> gain_free -> step on the device's own float32 tensors
+    (Environment.py:208-231, 255-273, 547-731 in the order marl_train_bcd.py:1307-1312, 1611 calls them)."""
+    h, b = c128(t["h_r"]), c128(t["b"])
+    dist = cpu(t["dist_r"]).astype(np.float64)
+    o_th, o_idx = orc.bcd_sweep(th_in, h, b, dist, bbit)
+    gap = orc.bcd_margin(th_in, h, b, bbit)
+    safe = np.minimum.accumulate(gap, axis=1) > 1e-9          # a flipped decision taints the rest of its sweep
+    return o_th, o_idx, safe, h, b
+
+
+@pytest.mark.parametrize("V,M,E", [(16, 256, 96), (8, 64, 300)])
+@pytest.mark.parametrize("bound", [False, True])
+def test_step_bcd_entry_vs_oracle(V, M, E, bound):
+    """The launch path BASELINE configs[4] is benchmarked through (bench.py --mode bcd): consecutive
+    `step(bcd=True)` / `bind_step(bcd=True)` calls against oracle `bcd_sweep -> gain_free -> step`, including the
+    bookkeeping the number depends on: the column sums stay cached, sweeps 2.. start from the sum the previous
+    sweep left in s_sum (`_ssum_sweeps` counts them), and Random_phase() / a direct theta write announced with
+    invalidate_colsum() force the re-summing pass."""
+    bbit = 3
+    rng = np.random.default_rng(100 * V + M + int(bound))
+    p = orc.OracleParams.yaml_effective()
+    env = make_vec(E, V, M, b=bbit, seed=17, yaml=True)
+    env.make_new_game()
+    env.renew_positions()
+    env.compute_parms()
+    env.Random_phase()
+    t = env.tensors
+    B0 = rng.uniform(0, 12, (E, V)).astype(np.float32)
+    t["data_buf"].copy_(torch.from_numpy(B0))
+    action, partner, ng, _ = random_step_inputs(E, V, rng)
+    a_dev = torch.from_numpy(action.astype(np.float32)).cuda()
+    pt, ngt = torch.from_numpy(partner.astype(np.int32)).cuda(), torch.from_numpy(ng.astype(np.int32)).cuda()
+    arr_dev = torch.zeros(E, V, dtype=torch.int32, device="cuda:0")
+    launch = env.bind_step(a_dev, pt, ngt, arr_dev, fused=True, bcd=True) if bound else None
+    assert env._colsum_valid and env._ssum_sweeps == 0
+
+    worst = dict(theta=0.0, gain=0.0, reward=0.0)
+
+    def one_step(expect_sweeps):
+        th_in = snap(c128(t["theta"]), bbit)
+        Bq, Qq = cpu(t["data_buf"]).astype(np.float64), cpu(t["mec_q"]).astype(np.float64)
+        arrivals = rng.poisson(1.0, (E, V))
+        arr_dev.copy_(torch.from_numpy(arrivals.astype(np.int32)))
+        a_dev.mul_(0.97)                                             # inputs are re-read on every launch
+        act = cpu(a_dev).astype(np.float64)
+        o_th, o_idx, safe, h, b = _bcd_step_reference(t, th_in, Bq, Qq, act, partner, ng, arrivals, p, bbit)
+        if bound:
+            launch()
+            out = (t["reward"], t["metrics"][:, 0], t["data_buf"])
+        else:
+            out = env.step(a_dev, pt, ngt, arr_dev, fused=True, bcd=True)
+        assert env._colsum_valid and env._ssum_sweeps == expect_sweeps
+        # (1) theta: same decisions as the oracle wherever float64 noise cannot flip one
+        th1 = c128(t["theta"])
+        assert safe.mean() > 0.97
+        err_th = np.abs(th1 - o_th)[safe]
+        worst["theta"] = max(worst["theta"], float(err_th.max()))
+        assert err_th.max() <= 1.5e-7
+        # the sum the sweep left behind is the sum of what it stored (the next sweep starts from it)
+        S = cpu(t["s_sum"]); S = S[:, 0] + 1j * S[:, 1]
+        want_S = np.sum(snap(th1, bbit) * (h.sum(axis=1) * b[None, :]), axis=1)
+        np.testing.assert_allclose(S, want_S, rtol=1e-10, atol=1e-10)
+        # (2) gains from the NEW theta (same launch sequence): 1e-5 + the float32 cancellation floor of an M-term sum
+        pl = cpu(t["pl"]).astype(np.float64)
+        img = np.einsum("em,evm,m->ev", th1, h, b)
+        gain = pl * np.abs(img) ** 2
+        g_dev = cpu(t["gain"]).astype(np.float64)
+        floor = pl * 2 * np.abs(img) * (3 * 6e-8 * M)
+        assert (np.abs(g_dev - gain) <= RT * gain + floor).all()
+        worst["gain"] = max(worst["gain"], float(np.max((np.abs(g_dev - gain) - floor) / gain)))
+        # and against the oracle's own sweep result for envs whose whole sweep is safe
+        env_safe = safe.all(axis=1)
+        assert env_safe.mean() > 0.5
+        g_orc = orc.gain_free(o_th, h, b, cpu(t["dist_r"]).astype(np.float64))
+        img_o = np.einsum("em,evm,m->ev", o_th, h, b)
+        # dist_r is float32 on the device: pl carries 2.2 * 6e-8 of that
+        assert (np.abs(g_dev - g_orc) <= RT * g_orc + pl * 2 * np.abs(img_o) * (3 * 6e-8 * M))[env_safe].all()
+        # (3) step outputs with the device's gains as input
+        o = orc.step(Bq, Qq, g_dev, act, partner, ng, arrivals, p)
+        near_qos, near_other = step_mask(o, partner, g_dev, Qq)
+        okr = check_step(env, out, o, Bq, p, near_qos, near_other)
+        assert okr.mean() > 0.97
+        rel = np.abs(cpu(out[0]) - o["reward"])[okr] / np.maximum(np.abs(o["reward"][okr]), 1e-3)
+        worst["reward"] = max(worst["reward"], float(rel.max()))
+
+    for k in range(4):                                   # sweep 1 re-sums, sweeps 2..4 take the cached-sum path
+        one_step(k + 1)
+    env.Random_phase()
+    assert env._ssum_sweeps == 0 and env._colsum_valid   # theta changed, geometry did not
+    one_step(1)
+    one_step(2)
+    put_complex(t["theta"], np.exp(1j * rng.uniform(0, 2 * np.pi, (E, M))))    # arbitrary (non-candidate) phases
+    env.invalidate_colsum()
+    assert env._ssum_sweeps == 0 and not env._colsum_valid
+    one_step(1)                                          # rebuilds c_col and re-sums
+    one_step(2)
+    print("step(bcd=True) V=%d M=%d bound=%s: max |dtheta| %.2e, gain rel err above floor %.2e, reward rel err %.2e"
+          % (V, M, bound, worst["theta"], worst["gain"], worst["reward"]))
+
+
+def test_step_bcd_flag_translation_equals_separate_calls():
+    """risvec_step_fused_bcd with REUSE flags == optimize_phase_shift() + step(fused=True), bit for bit, on every
+    combination of (cached column sums, cached sum) the host bookkeeping can produce."""
+    E, V, M = 257, 8, 64
+    rng = np.random.default_rng(7)
+    action, partner, ng, arrivals = random_step_inputs(E, V, rng)
+    a = torch.from_numpy(action.astype(np.float32)).cuda()
+    pt, ngt = torch.from_numpy(partner.astype(np.int32)).cuda(), torch.from_numpy(ng.astype(np.int32)).cuda()
+    ar = torch.from_numpy(arrivals.astype(np.int32)).cuda()
+    envs = []
+    for fused_entry in (True, False):
+        env = make_vec(E, V, M, seed=5, yaml=True)
+        env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase()
+        seen = []
+        for k in range(5):
+            if k == 3:
+                env.invalidate_colsum()                  # cold: column sums rebuilt + re-summed
+            if fused_entry:
+                env.step(a, pt, ngt, ar, fused=True, bcd=True)
+            else:
+                env.optimize_phase_shift()
+                env.step(a, pt, ngt, ar, fused=True)
+            seen.append((env._colsum_valid, env._ssum_sweeps))
+        envs.append((env, seen))
+    assert envs[0][1] == envs[1][1] == [(True, 1), (True, 2), (True, 3), (True, 1), (True, 2)]
+    for k in ("theta", "gain", "reward", "data_buf", "mec_q", "metrics", "obs", "s_sum"):
+        assert torch.equal(envs[0][0].tensors[k], envs[1][0].tensors[k]), k
+
+
+# ---------------------------------------------------------------------------- config 4: the gather, on the device
+def _check_gather(g, env, a, pt, ngt):
+    """start/wait twice (both halves of the double buffer) against obs.reshape while the env keeps stepping on
+    the main stream: the result must be the observation AT start(), not a later one."""
+    t = env.tensors
+    E, V = env.n_envs, env.n_veh
+    for rnd in range(4):
+        env.step(a, pt, ngt, None, fused=True)
+        want = t["obs"].reshape(E, 5 * V).clone()
+        out = g.start(t["obs"])
+        for _ in range(6):                               # overwrite obs several times while the gather is in flight
+            env.step(a, pt, ngt, None, fused=True)
+        g.wait()
+        assert out.shape == (g.world * E, 5 * V)
+        assert torch.equal(out[:E], want), rnd
+        assert not torch.equal(t["obs"].reshape(E, 5 * V), want)      # the env really moved on meanwhile
+    assert g.n_started == 4 and g.i == 0                 # two buffers, used alternately
+
+
+def _stepping_env(E=4096, V=8, M=64):
+    env = make_vec(E, V, M, seed=3, yaml=True)
+    env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase()
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy(rng.uniform(0, 1, (E, 2, V)).astype(np.float32)).cuda()
+    pt = torch.full((E, V), -1, dtype=torch.int32, device="cuda:0")
+    ngt = torch.full((E,), V, dtype=torch.int32, device="cuda:0")
+    return env, a, pt, ngt
+
+
+def test_joint_obs_gather_on_device_single_process():
+    from ris_vec_marl_amd import dist as rdist
+    env, a, pt, ngt = _stepping_env()
+    g = rdist.JointObsGather(env.n_envs, env.n_veh, env.device)
+    assert g.stream is not None and not g.collective and g.world == 1
+    _check_gather(g, env, a, pt, ngt)
+    with pytest.raises(ValueError):
+        g.start(env.tensors["obs"][:10])
+    # from a non-default main stream as well
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        env2, a2, pt2, ngt2 = _stepping_env(E=1024)
+        g2 = rdist.JointObsGather(env2.n_envs, env2.n_veh, env2.device)
+        _check_gather(g2, env2, a2, pt2, ngt2)
+    torch.cuda.synchronize()
+
+
+def test_joint_obs_gather_on_device_rccl_one_rank():
+    """The same through a real RCCL communicator: a one-rank `nccl` process group on cuda:0 (the collective is
+    issued on the side stream from the staged snapshot, exactly as with 8 ranks)."""
+    import torch.distributed as td
+    from ris_vec_marl_amd import dist as rdist
+    if td.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    td.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        env, a, pt, ngt = _stepping_env()
+        g = rdist.JointObsGather(env.n_envs, env.n_veh, env.device)
+        assert g.collective and g.backend == "nccl" and g.world == 1
+        _check_gather(g, env, a, pt, ngt)
+        joint = rdist.gather_joint_obs(env.tensors["obs"])
+        assert torch.equal(joint, env.tensors["obs"].reshape(env.n_envs, -1))
+        with pytest.raises(ValueError):
+            rdist.JointObsGather(8, 8, "cpu")            # RCCL cannot gather host tensors
+    finally:
+        td.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------- default device
+def test_objects_built_with_the_default_device_interoperate():
+    """Every constructor defaults to device="cuda"; torch compares `cuda` != `cuda:0`, so the device checks of
+    the bound launchers must see the resolved device.  Two rollout steps through every bind_* launcher."""
+    from ris_vec_marl_amd import (BatchedPolicy, EpisodeMeter, NomaGrouper, VecEnviron, VecReplayBuffer, apply_yaml_config,
+                                  reference_lanes)
+    L = reference_lanes()
+    E, V, M = 256, 8, 36
+    env = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3, n_envs=E, seed=1)
+    apply_yaml_config(env, None)
+    env.make_new_game(); env.compute_parms(); env.Random_phase(); env.update_channel_gains()
+    assert env.device == env.tensors["obs"].device and env.device.index is not None
+    grouper = NomaGrouper(env)
+    replay = VecReplayBuffer(8 * E, 5, V + 2, V)
+    policy = BatchedPolicy(V, 5, 64, 32)
+    meter = EpisodeMeter(env)
+    dev = env.device
+    action = torch.zeros(E, 2, V, device="cuda")
+    p01 = torch.zeros(E, V, device="cuda")
+    a_store = torch.zeros(E, V * (V + 2), device="cuda")
+    grouper.begin_episode(0)
+    mask = grouper.refresh_mask()
+    partner, ng = grouper.group(p01, 0)
+    assert partner.device == dev
+    step = env.bind_step(action, partner, ng, None, fused=True)
+    group = grouper.bind_group(p01)
+    store = replay.bind_store(None, a_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"], mask)
+    count = meter.bind(env)
+    meter.begin_episode()
+    for st in range(2):
+        policy.choose_action(env.observe(), mask, cpu_share_floor=float(env.cpu_share_floor), want_onehot=False,
+                             out=(action, p01, a_store))
+        group(st)                       # second step: prev_global = env metrics (the check ADVICE flagged)
+        step()
+        store(done=False, use_mask=True)
+        count()
+    grouper.group(p01, 2)               # the unbound form takes the same path
+    torch.cuda.synchronize()
+    assert replay.mem_cntr == 2 * E and torch.isfinite(env.tensors["reward"]).all()
+
+
+def test_observe_after_reset_and_checkpoint_guards():
+    """observe() after make_new_game() reflects the new DataBuf (marl_get_state reads live attributes,
+    marl_train_bcd.py:819-827); a checkpoint refuses an env with another seed / shard offset and carries power_w."""
+    E, V, M = 64, 8, 16
+    env = make_vec(E, V, M, seed=5, yaml=True)
+    env.make_new_game(); env.compute_parms(); env.Random_phase()
+    t = env.tensors
+    o0 = env.observe().clone()
+    assert torch.equal(o0[..., 0], t["data_buf"] / 10) and bool((o0[..., 1:] == 0).all())
+    a = torch.rand(E, 2, V, device="cuda:0")
+    pt = torch.full((E, V), -1, dtype=torch.int32, device="cuda:0"); ngt = torch.full((E,), V, dtype=torch.int32, device="cuda:0")
+    env.step(a, pt, ngt, None, fused=True)
+    o1 = env.observe().clone()
+    env.make_new_game()
+    o2 = env.observe()
+    assert torch.equal(o2[..., 0], t["data_buf"] / 10)                        # the new backlog
+    assert torch.equal(o2[..., 1:], o1[..., 1:])                              # data_t / data_p / rate survive a reset
+    sd = env.state_dict()
+    assert "power_w" in sd
+    for kw in (dict(seed=6), dict(env_offset=64)):
+        other = make_vec(E, V, M, **{**dict(seed=5), **kw}, yaml=True)
+        with pytest.raises(ValueError):
+            other.load_state_dict(sd)
+    twin = make_vec(E, V, M, seed=5, yaml=True)
+    twin.load_state_dict(sd)
+    assert torch.equal(twin.tensors["power_w"], t["power_w"]) and torch.equal(twin.observe(), env.observe())

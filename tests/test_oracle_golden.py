@@ -115,6 +115,39 @@ def test_step(V, which):
     assert (g["partner"] >= 0).any() and (g["partner"] == -1).any() and (g["partner"] == -2).any()
 
 
+@pytest.mark.parametrize("V", [4, 8])
+@pytest.mark.parametrize("which", ["default", "yaml"])
+def test_scalar_loop_step(V, which):
+    """oracle/risvec_scalar.py (the structure-faithful single-env form bench.py times as the CPU baseline)
+    against the reference's own outputs, sample by sample."""
+    from oracle import risvec_scalar as sc
+    g = load("step_%d_%s.npz" % (V, which))
+    p = orc.OracleParams() if which == "default" else orc.OracleParams.yaml_effective()
+    for e in range(0, g["gain"].shape[0], 3):
+        env = sc.ScalarEnv(V, 4, p, np.zeros(4), np.zeros((V, 4)), np.zeros(4), np.ones(V), g["data_buf0"][e], g["mec_q0"][e])
+        env.gain[:] = g["gain"][e]
+        groups = sc.groups_from_partner(g["partner"][e], g["n_groups"][e])
+        r = env.step(g["action"][e].copy(), groups, g["arrivals"][e])
+        for got, key in zip(r, ("reward", "global_reward", "data_buf", "data_t", "data_p", "over_power", "over_data")):
+            close(np.asarray(got), g[key][e], rtol=1e-12, atol=1e-300)
+        close(env.rate, g["vehicle_rate"][e], rtol=1e-12, atol=1e-300)
+        close(env.q, g["mec_q"][e], rtol=1e-12, atol=1e-300)
+        close(env.metrics14(float(r[1])), g["metrics"][e], rtol=1e-12, atol=1e-300)
+        close(env.power_eq, g["last_power_W"][e], rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("V,M", [(4, 16), (8, 64)])
+def test_scalar_loop_gain(V, M):
+    from oracle import risvec_scalar as sc
+    g = load("geometry_gain_%d_%d.npz" % (V, M))
+    p = orc.OracleParams()
+    for e in range(g["pos"].shape[0]):
+        env = sc.ScalarEnv(V, M, p, g["theta"][e], g["h_r"][e], g["b"], g["dist"][e], np.zeros(V))
+        env.update_channel_gains()
+        close(env.gain, g["gain"][e], rtol=1e-12)
+    assert sc.time_env_steps(4, 16, 0.05) >= 8            # the timing loop bench.py runs per core
+
+
 def test_trajectory_protocol():
     """a13-a15: obs formula, action map and call cadence against a recorded run."""
     g = load("trajectory_8_36.npz")
