@@ -279,6 +279,7 @@ class Case:
         n_groups = torch.from_numpy(ng_np).to(device)
         if mode == "cached":
             env.update_channel_gains()
+        self.multi = 1
         self.gather, self.gather_every = None, gather_every
         self.gather_note = "n/a (1 GPU)"
         if world > 1 and gather_every > 0:
@@ -336,6 +337,15 @@ class Case:
             phase = torch.from_numpy(rng.uniform(0, 2 * np.pi, (E, M)).astype(np.float32)).to(device)
             sp = SarlParams()
             launch = lambda: env.sarl_step(action, phase, None, sp, obs=full)       # noqa: E731
+        elif getattr(opts, "multi", 0) > 1:
+            if mode != "fused" or opts.noma or opts.meter or opts.steer:
+                raise SystemExit("--multi T is the T-step launch of the fused gains+step path (no --noma/--meter/--steer)")
+            T = int(opts.multi)
+            actions = torch.from_numpy(rng.uniform(0, 1, (T, E, 2, V)).astype(np.float32)).to(device)
+            traj = dict(reward=torch.empty(T, E, V, device=device), obs=torch.empty(T, E, V, 5, device=device),
+                        metrics=torch.empty(T, E, 16, device=device)) if full else {}
+            launch = env.bind_step_many(actions, partner, n_groups, None, metrics=full, obs=full, out=traj)
+            self.multi = T
         else:
             launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full,
                                    power_w=opts.meter, obs=full, steer=opts.steer and fused)
@@ -361,7 +371,8 @@ class Case:
             if self.marshal is not None:
                 self.marshal()
             self.group(t)
-        self.launch()
+        if self.multi == 1 or i % self.multi == 0:      # --multi T: one launch advances the envs by T steps
+            self.launch()
         if self.store is not None:
             self.store(done=(i % L) == L - 1, use_mask=(i % L) == 0)
         if self.meter is not None:
@@ -426,15 +437,24 @@ class Case:
 
 class _Opts:
     lean = steer = noma = replay = policy = meter = False
+    multi = 0
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
 
 
-def run_leg(name, E, V, M, mode, device, rank, world, steps, warmup, gather_every=0):
+def run_leg(name, E, V, M, mode, device, rank, world, steps, warmup, gather_every=0, multi=0):
     """A secondary workload measured in the same process with the same timing protocol."""
     start = rank * E
-    case = Case(E, V, M, mode, device, rank, world, start, _Opts(), gather_every)
+    case = Case(E, V, M, mode, device, rank, world, start, _Opts(multi=multi), gather_every)
     dt, kernel_ms = case.run(steps, warmup, world)
     per_env = case.per_env_bytes()
-    out = {"workload": "%s: %d envs/GPU x %d vehicles x %d RIS elements, %s" % (workload_name(E, V, M, mode, world), E, V, M, mode),
+    out = {"launch": ("one launch per step" if multi <= 1 else "T-step launch (risvec_step_fused_multi), T = %d: gains once per "
+                      "launch, queues in registers, every step's reward / obs / metrics recorded; the h_r read is "
+                      "amortised over T steps, so roofline_frac (per-step algorithmic bytes of SURVEY 8d) can exceed what "
+                      "HBM alone could deliver" % multi),
+           "workload": "%s: %d envs/GPU x %d vehicles x %d RIS elements, %s" % (workload_name(E, V, M, mode, world), E, V, M, mode),
            "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "env_steps_per_s": E * world * steps / dt,
            "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_env_step": per_env,
            "roofline_frac": per_env * E / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -542,6 +562,10 @@ def main() -> None:
     ap.add_argument("--meter", action="store_true",
                     help="f4: add every step's metrics / rewards / powers to the per-env episode accumulators "
                          "(EpisodeMeter) and reduce the episode scalars over the envs every 100 steps")
+    ap.add_argument("--multi", type=int, default=0, metavar="T",
+                    help="advance the envs by T steps per launch (risvec_step_fused_multi: actions [T,E,2,V], per-step "
+                         "reward / obs / metrics recorded) -- the launch shape for batches whose single step is shorter "
+                         "than a kernel launch; --steps is rounded up to a multiple of T")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)     # CPU launcher self-test (tests only)
     args = ap.parse_args()
     if args.policy:
@@ -557,6 +581,9 @@ def main() -> None:
         args.gather_every = cfg[4]
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.multi > 1:
+        args.steps = -(-args.steps // args.multi) * args.multi
+        args.warmup = -(-args.warmup // args.multi) * args.multi
 
     # ---- N > 1 without a launcher: become one, before anything touches a GPU
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -600,6 +627,7 @@ def main() -> None:
         if world == 1:
             legs["hbm_only"] = run_leg("hbm_only", 262144, 8, 64, "fused", device, rank, world, 200, 30)
             legs["c2"] = run_leg("c2", *CONFIGS["c2"][:4], device, rank, world, 2000, 200)
+            legs["c2_multi_step"] = run_leg("c2", *CONFIGS["c2"][:4], device, rank, world, 3200, 320, multi=32)
             legs["c4_shard"] = run_leg("c4_shard", *CONFIGS["c4"][:4], device, rank, world, 2000, 200)
             legs["c5"] = run_leg("c5", *CONFIGS["c5"][:4], device, rank, world, 200, 30)
             legs["cached"] = run_leg("cached", 32768, 8, 64, "cached", device, rank, world, 2000, 200)
@@ -644,6 +672,8 @@ def main() -> None:
                               % (4 * (10 * V + V * (V + 2) + V + 1 + V * V) + 1) if args.replay else "off"),
                    "policy": "BatchedPolicy 8x(5-512-256), every step" if args.policy else "synthetic outputs",
                    "steering_form": bool(args.steer and fused),
+                   "launch": ("one launch per step" if args.multi <= 1 else
+                              "T-step launch, T = %d (gains once per launch, per-step records written)" % args.multi),
                    "episode_meter": ("float64 episode sums of E x (17+V) columns every step, summary every 100 steps"
                                      if args.meter else "off"),
                    "agent_steps_per_s": E * world * args.steps / dt * V},

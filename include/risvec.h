@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 11
+#define RISVEC_ABI_VERSION 12
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -272,6 +272,29 @@ int risvec_data_rate(const RisVecState *s, const RisVecParams *p, const float *p
 int risvec_step_fused(const RisVecState *s, const RisVecParams *p, const float *action,
                       const int32_t *partner, const int32_t *n_groups, const int32_t *arrivals,
                       uint64_t seed, uint32_t counter, uint32_t flags, risvec_stream_t stream);
+
+/* Trajectory record of a multi-step launch: what the driver reads after every step (per-user rewards
+ * TRAIN:1611, the observation TRAIN:819-827, the metrics row TRAIN:1627-1662), one slice per step.
+ * Device pointers; any of them may be NULL (not recorded). */
+typedef struct RisVecTraj {
+    float *reward;          /* [T,E,V]                                                 */
+    float *obs;             /* [T,E,V,5]                                               */
+    float *metrics;         /* [T,E,16]                                                */
+} RisVecTraj;
+
+/* The T-step launch: exactly `n_steps` consecutive risvec_step_fused calls -- the driver's step loop
+ * marl_train_bcd.py:1304-1611 between two channel refreshes, with the NOMA groups frozen as they are inside an
+ * episode -- in ONE launch.  actions [T,E,2,V] (or [T,E,V,2] with RISVEC_STEP_POLICY_ACTION); arrivals [T,E,V]
+ * int32 or NULL (Philox, counter + t at step t, i.e. the counters T single calls would use); partner /
+ * n_groups are the same for every step.  The state tensors end up exactly as after the last of the T single calls
+ * (bit for bit); every step's reward / obs / metrics additionally go to traj (may be NULL).  h_r and theta
+ * cannot change inside the launch, so the cascaded gains are computed once and each env's queues stay in
+ * registers: at small batches (BASELINE configs[1]) this removes the per-step launch and memory round trip
+ * that bound a single-step launch.  RISVEC_STEP_REUSE_* / RISVEC_STEP_STEER are not accepted here. */
+int risvec_step_fused_multi(const RisVecState *s, const RisVecParams *p, int32_t n_steps, const float *actions,
+                            const int32_t *partner, const int32_t *n_groups, const int32_t *arrivals,
+                            uint64_t seed, uint32_t counter, uint32_t flags, const RisVecTraj *traj,
+                            risvec_stream_t stream);
 
 /* SARL variant: Simulation-SARL/Environment.py step(action_power, action_phase)
  * SENV:321-359 for every env: get_next_phase (theta = exp(j*action_phase), action_phase [E,M]

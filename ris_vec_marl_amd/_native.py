@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -71,6 +71,10 @@ class RisVecState(C.Structure):
         ("rate", _FP), ("data_t", _FP), ("data_p", _FP), ("reward", _FP), ("over_power", _FP),
         ("obs", _FP), ("metrics", _FP), ("power_w", _FP), ("c_col", _FP), ("s_sum", _FP), ("over_data", _FP), ("z_r", _FP),
     ]
+
+
+class RisVecTraj(C.Structure):
+    _fields_ = [("reward", _FP), ("obs", _FP), ("metrics", _FP)]
 
 
 class RisVecSarlParams(C.Structure):
@@ -139,6 +143,8 @@ _PROTOS = {
     "risvec_data_rate": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP, _FP, _FP, _FP]),
     "risvec_step_fused": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP, _FP,
                                     _FP, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
+    "risvec_step_fused_multi": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), C.c_int32, _FP, _FP, _FP, _FP,
+                                          C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(RisVecTraj), _FP]),
     "risvec_sarl_step": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecSarlParams), _FP, _FP, _FP,
                                    C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
     "risvec_step_fused_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP,

@@ -274,6 +274,10 @@ hipError_t launch_step(const RisVecState& s, const RisVecParams& p, const float*
         const hipError_t err = launch_step_steer(s, p, a, st);
         if (err != hipErrorNotSupported) return err;       // theta rows too long for LDS: stream h_r as usual
     }
+    if (fused) {                                                // small batch: latency-shaped single-group kernel
+        const hipError_t err = launch_step_fused_lat(s, p, a, st);
+        if (err != hipErrorNotSupported) return err;
+    }
     if (fused) {
         const hipError_t err = launch_step_fused_pipe(s, p, a, st);
         if (err != hipErrorNotSupported) return err;

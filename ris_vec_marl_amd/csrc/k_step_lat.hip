@@ -1,0 +1,249 @@
+// K34 for SMALL batches, and the multi-step launch.
+//
+// The software pipeline of k_step_pipe.hip hides HBM latency by giving every wavefront several env
+// groups to stream through a shallow register ring.  With few envs there is nothing to stream: at
+// BASELINE configs[1] (4 096 envs x 8 x 36) it degenerates to 512 single-group wavefronts (2 per CU)
+// that each walk 8 load units two at a time -- a chain of four dependent memory round trips, 7.7 us
+// for 13 MB (rocprofv3, profiles/r02a_c2_kernel_stats.csv), where a bare read of the same bytes takes
+// 2-3 us.  The kernels here are shaped for latency instead:
+//   * a wavefront owns EPWT <= 4 envs (not 64/VP), so even 4 096 envs make 2 048 wavefronts (8 per CU);
+//   * EVERY load of the wavefront -- its step() inputs, then all h_r / theta rows -- is issued before the
+//     first use: one memory round trip per wavefront, then the reduce, step() and the stores.
+// Same arithmetic in the same order as the pipelined kernel (same PipeShape, same transposing butterfly,
+// same step_core): results are bit-identical, which tests/test_entry_points_hip.py asserts.
+//
+// k_step_fused_lat<.., MULTI = true> is the T-step launch of SURVEY 7 ("launch latency"): n_steps
+// consecutive step() calls of the driver loop (marl_train_bcd.py:1304-1611 with the groups frozen, as
+// they are inside an episode) in ONE launch.  Envs never interact, so a wavefront simply keeps its
+// envs' queues (DataBuf, mec_queue_cycles) in registers and walks the steps: actions are read from
+// actions[t] (prefetched one step ahead), the Philox counter advances by one per step, each step's
+// trajectory record (reward / obs / metrics) goes to its slice of the trajectory buffers, and the
+// env's own tensors receive the last step's outputs -- bit-identical to n_steps single launches.
+// h_r and theta cannot change inside a launch, so the cascaded gains are computed once.
+//
+// Reference: Simulation-MARL-BCD/Environment.py update_channel_gains ENV:263-273 + step ENV:547-731.
+#include "risvec_pipe.hpp"
+
+namespace risvec {
+
+template <int V, int M, int EPWT, bool MULTI>
+__global__ void __launch_bounds__(kBlock)
+k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ) {
+    using S = PipeShape<V, M>;
+    constexpr int VP = S::VP, NP = S::NP, G = S::G, NIT = S::NIT, VPP = S::VPP;
+    constexpr int PC = S::PC, CHUNKS = S::CHUNKS, K = S::K;
+    constexpr int NU = EPWT * CHUNKS;                          // load units of the wavefront's envs
+    static_assert(EPWT >= 1 && EPWT <= S::EPW, "a wavefront holds at most 64/VP envs");
+    __shared__ float s_img[kBlock / kWave][kWave * 2];
+
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int gl = lane % G, gv = lane / G;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    const int e0 = wid * EPWT;
+    if (e0 >= d.E) return;                                     // whole wave
+    const int v_mine = lane % VP, e_mine = e0 + lane / VP;
+    const bool active = (lane / VP) < EPWT && e_mine < d.E;
+
+    // step() inputs first: they are used last, and loads return in issue order
+    StepIn in = load_step_in(d, A, e_mine, v_mine, active);
+
+    const float4* __restrict__ h4 = reinterpret_cast<const float4*>(A.h_r);
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(A.theta);
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(A.b);
+    const int e_last = d.E - 1;
+    const unsigned lane_off = (unsigned)(gv * NP + gl);
+
+    float4 bq[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = gl + it * G;
+        bq[it] = p < NP ? b4[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // Units are loaded in batches of up to 4 (all of them when the wavefront owns <= 4 envs: one memory
+    // round trip); the multi-step form may own 64/VP envs, where the gain phase is amortised over the steps.
+    constexpr int UB = NU > 4 ? 4 : NU;
+    static_assert(NU % UB == 0, "unit batches must tile the wavefront's units");
+    float2 w0[NIT], w1[NIT];
+#pragma unroll
+    for (int b0 = 0; b0 < NU; b0 += UB) {
+        Unit<PC, NIT> u[UB];
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const int ui = b0 + k;
+            const int i = ui / CHUNKS, c = ui % CHUNKS;
+            int e = e0 + i;
+            e = e < e_last ? e : e_last;                       // tail: re-read the last env, masked later
+            const float4* __restrict__ hb = h4 + (long long)e * (V * NP);
+            const float4* __restrict__ tb = t4 + (long long)e * NP;
+#pragma unroll
+            for (int pc = 0; pc < PC; ++pc) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int p = gl + it * G;
+                    u[k].h[pc][it] = (NP % G == 0 || p < NP) ? hb[lane_off + ((c * PC + pc) * VPP * NP + it * G)]
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (c == 0) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int p = gl + it * G;
+                    u[k].t[it] = (NP % G == 0 || p < NP) ? tb[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const int ui = b0 + k;
+            const int i = ui / CHUNKS, c = ui % CHUNKS;
+            if (c == 0) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    w0[it] = cmul(make_float2(u[k].t[it].x, u[k].t[it].y), make_float2(bq[it].x, bq[it].y));
+                    w1[it] = cmul(make_float2(u[k].t[it].z, u[k].t[it].w), make_float2(bq[it].z, bq[it].w));
+                }
+            }
+            float val[8];
+#pragma unroll
+            for (int pc = 0; pc < PC; ++pc) {
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    acc = cfma(make_float2(u[k].h[pc][it].x, u[k].h[pc][it].y), w0[it], acc);
+                    acc = cfma(make_float2(u[k].h[pc][it].z, u[k].h[pc][it].w), w1[it], acc);
+                }
+                val[2 * pc] = acc.x;
+                val[2 * pc + 1] = acc.y;
+            }
+            treduce<K, G / 2>(val, gl);
+            if (gl % S::WSTRIDE == 0) {
+                const int j = gl / S::WSTRIDE;
+                const int v = (c * PC + (j >> 1)) * VPP + gv;
+                s_img[wave][(i * VP + v) * 2 + (j & 1)] = val[0];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                           // own LDS writes -> own reads (in order per wave)
+    const float2 img = *reinterpret_cast<const float2*>(&s_img[wave][lane * 2]);
+    const long long idx = (long long)e_mine * V + v_mine;
+    float g = 0.f;
+    if (active) {
+        g = gain_from_img(img, in.pl, A.h_d, idx);
+        A.gain[idx] = g;
+    }
+    if constexpr (!MULTI) {
+        step_core<VP>(d, P, A, e_mine, v_mine, active, g, in);
+    } else {
+        const long long ev = (long long)d.E * V;
+        const bool pol = (A.flags & RISVEC_STEP_POLICY_ACTION) != 0;
+        StepArgs At = A;
+#pragma unroll 1
+        for (int t = 0; t < n_steps; ++t) {
+            // next step's action: in flight during this step's arithmetic (clamped on the last step)
+            const int tn = t + 1 < n_steps ? t + 1 : t;
+            const float* an = A.action + (long long)tn * 2 * ev;
+            float a0n = 0.f, a1n = 0.f;
+            if (active) {
+                if (pol) {
+                    const float2 pa = *reinterpret_cast<const float2*>(an + idx * 2);
+                    a0n = pa.x; a1n = pa.y;
+                } else {
+                    a0n = an[(long long)e_mine * 2 * V + v_mine];
+                    a1n = an[(long long)e_mine * 2 * V + V + v_mine];
+                }
+            }
+            At.counter = A.counter + (uint32_t)t;
+            At.arrivals = A.arrivals ? A.arrivals + (long long)t * ev : nullptr;
+            StepTraj tj;
+            tj.reward = TJ.reward ? TJ.reward + (long long)t * ev : nullptr;
+            tj.obs = TJ.obs ? TJ.obs + (long long)t * ev * 5 : nullptr;
+            tj.metrics = TJ.metrics ? TJ.metrics + (long long)t * d.E * RISVEC_METRICS : nullptr;
+            tj.store_state = t == n_steps - 1;
+            const StepCarry c = step_core<VP, true>(d, P, At, e_mine, v_mine, active, g, in, &tj);
+            in.B = c.B;
+            in.Q0 = c.Q;
+            in.a0 = a0n;
+            in.a1 = a1n;
+        }
+    }
+}
+
+// envs per wavefront: as many as keep >= 8 wavefronts per CU in flight (measured: see DESIGN.md section 6)
+static int lat_epwt(int n_envs, int max_epw) {
+    static const int forced = [] { const char* s = std::getenv("RISVEC_LAT_EPW"); return s ? std::atoi(s) : -1; }();
+    if (forced >= 0) return forced;                            // 0 disables the latency-shaped single-step kernel
+    const long long want = 8LL * num_cus();
+    int e = 4;
+    while (e > 1 && (long long)n_envs / e < want) e >>= 1;
+    return e < max_epw ? e : max_epw;
+}
+
+template <int V, int M, int EPWT, bool MULTI>
+static hipError_t launch_lat_shape(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                                   const RisVecTraj& tj, hipStream_t st) {
+    const long long waves = ((long long)s.n_envs + EPWT - 1) / EPWT;
+    const unsigned grid = (unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave));
+    hipLaunchKernelGGL((k_step_fused_lat<V, M, EPWT, MULTI>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_steps, tj);
+    return hipGetLastError();
+}
+
+template <int V, int M, bool MULTI>
+static hipError_t launch_lat_vm(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                                const RisVecTraj& tj, int epwt, hipStream_t st) {
+    switch (epwt) {
+        case 1: return launch_lat_shape<V, M, 1, MULTI>(s, p, a, n_steps, tj, st);
+        case 2: return launch_lat_shape<V, M, 2, MULTI>(s, p, a, n_steps, tj, st);
+        case 4: return launch_lat_shape<V, M, 4, MULTI>(s, p, a, n_steps, tj, st);
+        case 8:
+            // all 64 lanes stepping: only worth its registers where the step loop dominates (the T-step launch)
+            if constexpr (MULTI) return launch_lat_shape<V, M, 8, MULTI>(s, p, a, n_steps, tj, st);
+            return hipErrorNotSupported;
+        default: return hipErrorNotSupported;
+    }
+}
+
+template <bool MULTI>
+static hipError_t dispatch_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                               const RisVecTraj& tj, int epwt, hipStream_t st) {
+    const int V = s.n_veh, M = s.n_ris;
+    if (V == 8 && M == 64) return launch_lat_vm<8, 64, MULTI>(s, p, a, n_steps, tj, epwt, st);
+    if (V == 8 && M == 36) return launch_lat_vm<8, 36, MULTI>(s, p, a, n_steps, tj, epwt, st);
+    if (V == 8 && M == 40) return launch_lat_vm<8, 40, MULTI>(s, p, a, n_steps, tj, epwt, st);
+    if (V == 4 && M == 16) return launch_lat_vm<4, 16, MULTI>(s, p, a, n_steps, tj, epwt, st);
+    return hipErrorNotSupported;
+}
+
+// Single step, small batch: taken instead of the software pipeline when the pipeline could not even give
+// every CU 8 wavefronts of 64/VP envs (n_envs < 8 CUs x 64/VP x ...); hipErrorNotSupported otherwise.
+hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
+    const int vp = pow2_ceil(s.n_veh);
+    const int epw = kWave / vp;
+    static const long long limit = [] {                        // envs below which the latency shape wins
+        const char* e = std::getenv("RISVEC_LAT_MAX_ENVS");
+        return e ? std::atoll(e) : 10240LL;
+    }();
+    if ((long long)s.n_envs > limit) return hipErrorNotSupported;
+    const int epwt = lat_epwt(s.n_envs, epw);
+    if (epwt <= 0) return hipErrorNotSupported;
+    const RisVecTraj none{nullptr, nullptr, nullptr};
+    return dispatch_lat<false>(s, p, a, 1, none, epwt, st);
+}
+
+// n_steps consecutive fused steps in one launch; hipErrorNotSupported when the shape has no
+// compile-time kernel (the caller then issues n_steps single launches).
+hipError_t launch_step_fused_multi(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                                   const RisVecTraj* traj, hipStream_t st) {
+    // The step loop is instruction-issue-bound (one step() is ~400 dependent-ish vector instructions per
+    // wavefront whatever the number of active lanes), so a wavefront should carry as many envs as it has
+    // lanes for -- as long as every SIMD still gets a wavefront (4 per CU).
+    int epw = kWave / pow2_ceil(s.n_veh);
+    if (epw > 8) epw = 8;
+    static const int forced = [] { const char* e = std::getenv("RISVEC_MULTI_EPW"); return e ? std::atoi(e) : 0; }();
+    int epwt = epw;
+    while (epwt > 1 && (long long)s.n_envs / epwt < 4LL * num_cus()) epwt >>= 1;
+    if (forced > 0) epwt = forced;
+    const RisVecTraj tj = traj ? *traj : RisVecTraj{nullptr, nullptr, nullptr};
+    return dispatch_lat<true>(s, p, a, n_steps, tj, epwt, st);
+}
+
+}  // namespace risvec

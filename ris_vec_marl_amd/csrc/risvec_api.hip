@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "risvec_launch.hpp"
+#include "risvec_step.hpp"
 
 namespace {
 
@@ -268,6 +269,42 @@ int risvec_step_fused(const RisVecState* s, const RisVecParams* p, const float* 
     if (int rc = check_step(fn, s, action, partner, n_groups, arrivals, flags, true)) return rc;
     return finish(fn, risvec::launch_step(*s, *p, action, partner, n_groups, arrivals, seed, counter, flags,
                                           true, (hipStream_t)stream));
+}
+
+int risvec_step_fused_multi(const RisVecState* s, const RisVecParams* p, int32_t n_steps, const float* actions,
+                            const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals, uint64_t seed,
+                            uint32_t counter, uint32_t flags, const RisVecTraj* traj, risvec_stream_t stream) {
+    const char* fn = "risvec_step_fused_multi";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    if (n_steps < 1 || n_steps > (1 << 20)) return fail(RISVEC_ERR_ARG, "%s: n_steps=%d outside [1, 2^20]", fn, n_steps);
+    if (flags & (RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_STEER))
+        return fail(RISVEC_ERR_ARG, "%s: the BCD / steering flags (0x%x) are not accepted by the multi-step launch", fn, flags);
+    if (int rc = check_step(fn, s, actions, partner, n_groups, arrivals, flags, true)) return rc;
+    if (traj) { OPT_PTR(traj->reward, "traj.reward"); OPT_PTR(traj->obs, "traj.obs"); OPT_PTR(traj->metrics, "traj.metrics"); }
+    hipStream_t st = (hipStream_t)stream;
+    const risvec::StepArgs a = risvec::make_step_args(*s, actions, partner, n_groups, arrivals, seed, counter, flags);
+    const hipError_t err = risvec::launch_step_fused_multi(*s, *p, a, n_steps, traj, st);
+    if (err != hipErrorNotSupported) return finish(fn, err);
+    // shapes without a compile-time kernel: the same thing as n_steps launches, records copied out after each
+    const long long ev = (long long)s->n_envs * s->n_veh;
+    for (int t = 0; t < n_steps; ++t) {
+        const hipError_t e1 = risvec::launch_step(*s, *p, actions + (long long)t * 2 * ev, partner, n_groups,
+                                                  arrivals ? arrivals + (long long)t * ev : nullptr, seed,
+                                                  counter + (uint32_t)t, flags, true, st);
+        if (e1 != hipSuccess) return finish(fn, e1);
+        if (traj) {
+            hipError_t e2 = hipSuccess;
+            if (traj->reward) e2 = hipMemcpyAsync(traj->reward + t * ev, s->reward, ev * 4, hipMemcpyDeviceToDevice, st);
+            if (e2 == hipSuccess && traj->obs && (flags & RISVEC_STEP_OBS))
+                e2 = hipMemcpyAsync(traj->obs + t * ev * 5, s->obs, ev * 20, hipMemcpyDeviceToDevice, st);
+            if (e2 == hipSuccess && traj->metrics)
+                e2 = hipMemcpyAsync(traj->metrics + (long long)t * s->n_envs * RISVEC_METRICS, s->metrics,
+                                    (size_t)s->n_envs * RISVEC_METRICS * 4, hipMemcpyDeviceToDevice, st);
+            if (e2 != hipSuccess) return finish(fn, e2);
+        }
+    }
+    return RISVEC_OK;
 }
 
 int risvec_sarl_step(const RisVecState* s, const RisVecSarlParams* p, const float* action_power,

@@ -100,8 +100,10 @@ __host__ __device__ constexpr int pow2_ceil(int x) {
 }
 
 // complex helpers on float2 = (re, im)
+// (explicit fused forms: an `a*b - c*d` expression leaves the choice of which product is fused to the
+// compiler, and it chose differently in different kernels -- results must not depend on the kernel taken)
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 __device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 acc) {
     acc.x = fmaf(a.x, b.x, acc.x);

@@ -156,9 +156,9 @@ __device__ __forceinline__ float gain_from_img(float2 img, float pl, const float
         const float a = sqrtf(pl);
         const float2 hd = *reinterpret_cast<const float2*>(h_d + idx * 2);
         const float re = fmaf(a, img.x, hd.x), im = fmaf(a, img.y, hd.y);
-        return re * re + im * im;
+        return fmaf(re, re, im * im);
     }
-    return pl * (img.x * img.x + img.y * img.y);
+    return pl * fmaf(img.x, img.x, img.y * img.y);     // explicit: the same rounding in every kernel
 }
 
 // ---------------------------------------------------------------------------
@@ -209,13 +209,30 @@ inline int pick_group(int M, int vec, int VP) {
     return g;
 }
 
+// Per-step extras of the multi-step launch (risvec_step_fused_multi): where this step's trajectory
+// record goes (pointers already offset to the step's slice; nullptr = not recorded) and whether the
+// env's own state / output tensors are written (only the last step of a launch needs to).
+struct StepTraj {
+    float* reward;      // [E,V]
+    float* obs;         // [E,V,5]
+    float* metrics;     // [E,16]
+    bool store_state;
+};
+
+// new queue state a step leaves behind (kept in registers across the steps of one launch)
+struct StepCarry {
+    float B, Q;
+};
+
 // ---------------------------------------------------------------------------
 // step() for one (env, vehicle) lane.  Called by ALL 64 lanes (cross-lane ops inside);
-// `active` masks lanes beyond V or E.
+// `active` masks lanes beyond V or E.  TRAJ = false is the single-step form (every output
+// goes to the env's tensors); TRAJ = true additionally honours `tj`.
 // ---------------------------------------------------------------------------
-template <int VP>
-__device__ __forceinline__ void step_core(const Dims& d, const RisVecParams& P, const StepArgs& A,
-                                          int e, int v, bool active, float gain, const StepIn& in) {
+template <int VP, bool TRAJ = false>
+__device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams& P, const StepArgs& A,
+                                               int e, int v, bool active, float gain, const StepIn& in,
+                                               const StepTraj* tj = nullptr) {
     const int V = d.V;
     const long long idx = (long long)e * V + v;
     const float eps = 1e-12f;
@@ -318,7 +335,9 @@ __device__ __forceinline__ void step_core(const Dims& d, const RisVecParams& P, 
     const float rew_sum = gsum<VP>(active ? rew : 0.f);
     const float inv_v = __builtin_amdgcn_rcpf((float)V);
 
-    if (active) {
+    bool store_state = true;
+    if constexpr (TRAJ) store_state = tj->store_state;
+    if (active && store_state) {
         A.data_buf[idx] = Bn;
         A.rate[idx] = rate;
         A.data_t[idx] = data_t;
@@ -337,6 +356,15 @@ __device__ __forceinline__ void step_core(const Dims& d, const RisVecParams& P, 
         }
         if (v == 0) A.mec_q[e] = Q;
     }
+    if constexpr (TRAJ) {
+        if (active) {
+            if (tj->reward) tj->reward[idx] = rew;
+            if (tj->obs) {
+                float* o = tj->obs + idx * 5;
+                o[0] = Bn * 0.1f; o[1] = data_t * 0.1f; o[2] = data_p * 0.1f; o[3] = 0.f; o[4] = rate * 0.05f;
+            }
+        }
+    }
 
     if (A.flags & RISVEC_STEP_METRICS) {
         const float z = 0.f;
@@ -352,15 +380,28 @@ __device__ __forceinline__ void step_core(const Dims& d, const RisVecParams& P, 
         const float s_de = gsum<VP>(active ? delay : z);
         const float s_en = gsum<VP>(active ? energy : z);
         if (active && v == 0) {
-            float4* m = reinterpret_cast<float4*>(A.metrics + (long long)e * RISVEC_METRICS);
-            m[0] = make_float4(rew_sum * inv_v, s_off, s_dp, Q);
-            m[1] = make_float4(s_b * inv_v, s_dl * inv_v, s_dq * inv_v, s_dc * inv_v);
-            m[2] = make_float4(s_tx * inv_v, fdiv(svc, edge_cap + 1e-12f), s_ut * inv_v, s_vi * inv_v);
-            m[3] = make_float4(s_de * inv_v, s_en * inv_v, 0.f, 0.f);
+            const float4 m0 = make_float4(rew_sum * inv_v, s_off, s_dp, Q);
+            const float4 m1 = make_float4(s_b * inv_v, s_dl * inv_v, s_dq * inv_v, s_dc * inv_v);
+            const float4 m2 = make_float4(s_tx * inv_v, fdiv(svc, edge_cap + 1e-12f), s_ut * inv_v, s_vi * inv_v);
+            const float4 m3 = make_float4(s_de * inv_v, s_en * inv_v, 0.f, 0.f);
+            if (store_state) {
+                float4* m = reinterpret_cast<float4*>(A.metrics + (long long)e * RISVEC_METRICS);
+                m[0] = m0; m[1] = m1; m[2] = m2; m[3] = m3;
+            }
+            if constexpr (TRAJ) {
+                if (tj->metrics) {
+                    float4* m = reinterpret_cast<float4*>(tj->metrics + (long long)e * RISVEC_METRICS);
+                    m[0] = m0; m[1] = m1; m[2] = m2; m[3] = m3;
+                }
+            }
         }
     } else if (active && v == 0) {
-        A.metrics[(long long)e * RISVEC_METRICS] = rew_sum * inv_v;          // global_reward only
+        if (store_state) A.metrics[(long long)e * RISVEC_METRICS] = rew_sum * inv_v;          // global_reward only
+        if constexpr (TRAJ) {
+            if (tj->metrics) tj->metrics[(long long)e * RISVEC_METRICS] = rew_sum * inv_v;
+        }
     }
+    return StepCarry{Bn, Q};
 }
 
 inline StepArgs make_step_args(const RisVecState& s, const float* action, const int32_t* partner,
@@ -381,5 +422,9 @@ inline StepArgs make_step_args(const RisVecState& s, const float* action, const 
 hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, const StepArgs& a,
                                   hipStream_t st);
 hipError_t launch_gain_pipe(const RisVecState& s, hipStream_t st);
+// latency-shaped single-group kernels for small batches and the multi-step launch (k_step_lat.hip)
+hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st);
+hipError_t launch_step_fused_multi(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                                   const RisVecTraj* traj, hipStream_t st);
 
 }  // namespace risvec

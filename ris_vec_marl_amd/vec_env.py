@@ -385,6 +385,87 @@ class VecEnviron(ParamAttrs):
         return (t["reward"], t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"],
                 t["over_data"])
 
+    def step_many(self, actions, partner, n_groups, arrivals=None, metrics: bool = True, power_w: bool = False,
+                  obs: bool = True, policy_action: bool = False, record: Sequence[str] = ("reward", "obs", "metrics"),
+                  out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """T consecutive fused `step()` calls in ONE launch (`risvec_step_fused_multi`): the driver's step loop
+        marl_train_bcd.py:1304-1611 between two channel refreshes with the NOMA groups frozen, as they are
+        inside an episode.  actions [T,E,2,V] float32 (or [T,E,V,2] with policy_action=True); partner / n_groups as
+        for `step()` (the same for every step); arrivals [T,E,V] int32 injected draws or None (Philox with the
+        counters T single calls would use).  The env's tensors end up exactly as after the last of T single
+        `step(..., fused=True)` calls, bit for bit; `record` names the per-step records to keep
+        ("reward" [T,E,V], "obs" [T,E,V,5], "metrics" [T,E,16]) -- returned as a dict, written into `out`'s
+        tensors when given.  h_r / theta cannot change inside the launch, so the gains are computed once and each
+        env's queues stay in registers: this is the launch to use when a batched step is shorter than a kernel
+        launch (small E)."""
+        self._ensure_device()
+        E, V = self.n_envs, self.n_veh
+        a = torch.as_tensor(actions)
+        if a.dim() != 4 or tuple(a.shape[1:]) != ((E, V, 2) if policy_action else (E, 2, V)):
+            raise ValueError("actions must have shape [T, %d, %s]" % (E, "%d, 2" % V if policy_action else "2, %d" % V))
+        T = int(a.shape[0])
+        if T < 1:
+            raise ValueError("actions holds no step")
+        a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        pt = self._arg(partner, torch.int32, (E, V), "partner")
+        ng = self._arg(n_groups, torch.int32, (E,), "n_groups")
+        ar = self._arg(arrivals, torch.int32, (T, E, V), "arrivals")
+        shapes = {"reward": (T, E, V), "obs": (T, E, V, 5), "metrics": (T, E, N.METRICS)}
+        rec: Dict[str, torch.Tensor] = {}
+        for k in record:
+            if k not in shapes:
+                raise ValueError("record: unknown trajectory record %r (choose from %s)" % (k, sorted(shapes)))
+            if k == "obs" and not obs:
+                raise ValueError("record 'obs' needs obs=True")
+            if out is not None and k in out:
+                rec[k] = self._bound(out[k], torch.float32, shapes[k], "out[%r]" % k)
+            else:
+                rec[k] = torch.empty(shapes[k], dtype=torch.float32, device=self.device)
+        tj = N.RisVecTraj(_dev_ptr(rec.get("reward")), _dev_ptr(rec.get("obs")), _dev_ptr(rec.get("metrics")))
+        flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
+                 | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0))
+        N.check(N.load().risvec_step_fused_multi(C.byref(self._cstate), C.byref(self._p()), T, _dev_ptr(a), _dev_ptr(pt),
+                                                 _dev_ptr(ng), _dev_ptr(ar), self.seed, self._steps, flags, C.byref(tj),
+                                                 self._stream()))
+        self._steps += T
+        self._obs_stale = not obs
+        return rec
+
+    def bind_step_many(self, actions: torch.Tensor, partner: torch.Tensor, n_groups: torch.Tensor,
+                       arrivals: Optional[torch.Tensor] = None, metrics: bool = True, power_w: bool = False,
+                       obs: bool = True, policy_action: bool = False,
+                       out: Optional[Dict[str, torch.Tensor]] = None):
+        """`step_many` validated and marshalled once: returns a zero-argument launcher that advances the env by
+        T steps per call, reading `actions` [T,E,...] (and `arrivals`) in place and writing the per-step records
+        into `out`'s tensors ("reward" [T,E,V], "obs" [T,E,V,5], "metrics" [T,E,16]; any subset)."""
+        self._ensure_device()
+        E, V = self.n_envs, self.n_veh
+        if not isinstance(actions, torch.Tensor) or actions.dim() != 4:
+            raise ValueError("actions must be a [T, E, ...] device tensor")
+        T = int(actions.shape[0])
+        a = self._bound(actions, torch.float32, (T, E, V, 2) if policy_action else (T, E, 2, V), "actions")
+        pt = self._bound(partner, torch.int32, (E, V), "partner")
+        ng = self._bound(n_groups, torch.int32, (E,), "n_groups")
+        ar = self._bound(arrivals, torch.int32, (T, E, V), "arrivals")
+        shapes = {"reward": (T, E, V), "obs": (T, E, V, 5), "metrics": (T, E, N.METRICS)}
+        rec = {k: self._bound(t, torch.float32, shapes[k], "out[%r]" % k) for k, t in (out or {}).items()}
+        tj = N.RisVecTraj(_dev_ptr(rec.get("reward")), _dev_ptr(rec.get("obs")), _dev_ptr(rec.get("metrics")))
+        flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
+                 | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0))
+        fn, cs, seed, stream = N.load().risvec_step_fused_multi, C.byref(self._cstate), C.c_uint64(self.seed), self._stream()
+        pa, pp, pn, par, ptj = _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng), _dev_ptr(ar), C.byref(tj)
+
+        def launch() -> None:
+            rc = fn(cs, C.byref(self._p()), T, pa, pp, pn, par, seed, self._steps, flags, ptj, stream)
+            if rc:
+                N.check(rc)
+            self._steps += T
+            self._obs_stale = not obs
+
+        launch.inputs = (a, pt, ng, ar, rec, tj)
+        launch.n_steps = T
+        return launch
+
     def sarl_step(self, action_power, action_phase=None, arrivals=None, sarl_params=None, obs: bool = True
                   ) -> Tuple[torch.Tensor, ...]:
         """The single-agent variant's step (Simulation-SARL/Environment.py:321-359) for every env:

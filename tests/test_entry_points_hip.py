@@ -283,3 +283,107 @@ def test_observe_after_reset_and_checkpoint_guards():
     twin = make_vec(E, V, M, seed=5, yaml=True)
     twin.load_state_dict(sd)
     assert torch.equal(twin.tensors["power_w"], t["power_w"]) and torch.equal(twin.observe(), env.observe())
+
+
+# ---------------------------------------------------------------------------- small batches / the T-step launch
+def _rollout_env(E, V, M, seed=9):
+    env = make_vec(E, V, M, seed=seed, yaml=True)
+    env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase()
+    return env
+
+
+@pytest.mark.parametrize("E,V,M", [(4096, 8, 36), (8192, 8, 64), (1000, 8, 40), (515, 4, 16), (1, 8, 64), (3, 8, 36)])
+def test_small_batch_kernel_is_the_pipelined_kernel_bit_for_bit(E, V, M):
+    """Below ~12k envs `risvec_step_fused` takes the latency-shaped single-group kernel (k_step_lat.hip); same
+    arithmetic in the same order as the software pipeline, so every output must be identical.  RISVEC_LAT_MAX_ENVS=0
+    in a child process forces the pipeline for the comparison (the switch is read once per process)."""
+    import subprocess
+    import sys
+    import tempfile
+    rng = np.random.default_rng(E + M)
+    action, partner, ng, arrivals = random_step_inputs(E, V, rng)
+    env = _rollout_env(E, V, M)
+    for _ in range(3):
+        env.step(action.astype(np.float32), partner.astype(np.int32), ng.astype(np.int32), arrivals.astype(np.int32), fused=True)
+    keys = ("gain", "reward", "data_buf", "mec_q", "rate", "data_t", "data_p", "over_power", "obs", "metrics", "power_w")
+    mine = {k: cpu(env.tensors[k]).copy() for k in keys}
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), action=action, partner=partner, ng=ng, arrivals=arrivals)
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from tests.test_entry_points_hip import _rollout_env, cpu\n"
+            "z = np.load(%r)\n"
+            "env = _rollout_env(%d, %d, %d)\n"
+            "for _ in range(3):\n"
+            "    env.step(z['action'].astype(np.float32), z['partner'].astype(np.int32), z['ng'].astype(np.int32), z['arrivals'].astype(np.int32), fused=True)\n"
+            "np.savez(%r, **{k: cpu(env.tensors[k]) for k in %r})\n"
+        ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(tmp, "in.npz"), E, V, M,
+             os.path.join(tmp, "out.npz"), keys)
+        e = dict(os.environ, RISVEC_LAT_MAX_ENVS="0")
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        other = np.load(os.path.join(tmp, "out.npz"))
+        for k in keys:
+            assert np.array_equal(mine[k], other[k]), k
+
+
+@pytest.mark.parametrize("E,V,M,T", [(4096, 8, 36, 7), (8192, 8, 64, 4), (301, 8, 40, 5), (77, 4, 16, 3), (40000, 8, 64, 3),
+                                     (130, 5, 21, 4), (64, 16, 256, 2), (9, 8, 64, 1)])
+@pytest.mark.parametrize("inject", [False, True])
+def test_multi_step_launch_equals_single_launches(E, V, M, T, inject):
+    """risvec_step_fused_multi == T consecutive risvec_step_fused calls, bit for bit: final state and outputs, and
+    every step's trajectory record equals what the env's tensors held after that single step (compile-time shapes
+    take the one-launch kernel; (5,21) and (16,256) go through the documented launch-per-step form)."""
+    rng = np.random.default_rng(E + M + T)
+    _, partner, ng, _ = random_step_inputs(E, V, rng)
+    actions = rng.uniform(-0.1, 1.2, (T, E, 2, V)).astype(np.float32)
+    arrivals = rng.poisson(1.0, (T, E, V)).astype(np.int32) if inject else None
+    pt, ngt = partner.astype(np.int32), ng.astype(np.int32)
+    keys = ("gain", "reward", "data_buf", "mec_q", "rate", "data_t", "data_p", "over_power", "obs", "metrics")
+    one = _rollout_env(E, V, M)
+    per_step = []
+    for t in range(T):
+        one.step(actions[t], pt, ngt, None if arrivals is None else arrivals[t], fused=True, power_w=False)
+        per_step.append({k: cpu(one.tensors[k]).copy() for k in ("reward", "obs", "metrics")})
+    many = _rollout_env(E, V, M)
+    rec = many.step_many(actions, pt, ngt, arrivals)
+    assert many._steps == one._steps == T
+    for k in keys:
+        assert np.array_equal(cpu(many.tensors[k]), cpu(one.tensors[k])), k
+    for t in range(T):
+        for k in ("reward", "obs", "metrics"):
+            assert np.array_equal(cpu(rec[k][t]), per_step[t][k]), (t, k)
+    # and the launch after it continues the same Philox stream / state
+    one.step(actions[0], pt, ngt, None, fused=True, power_w=False)
+    many.step(actions[0], pt, ngt, None, fused=True, power_w=False)
+    assert torch.equal(many.tensors["data_buf"], one.tensors["data_buf"])
+
+
+def test_multi_step_launch_options_and_errors():
+    E, V, M, T = 300, 8, 36, 3
+    rng = np.random.default_rng(0)
+    _, partner, ng, _ = random_step_inputs(E, V, rng)
+    pt, ngt = partner.astype(np.int32), ng.astype(np.int32)
+    pol = rng.uniform(-1.2, 1.2, (T, E, V, 2)).astype(np.float32)
+    a, b = _rollout_env(E, V, M), _rollout_env(E, V, M)
+    for t in range(T):
+        a.step(pol[t], pt, ngt, None, fused=True, policy_action=True)
+    out = {"reward": torch.empty(T, E, V, device="cuda:0")}
+    rec = b.step_many(pol, pt, ngt, None, policy_action=True, record=("reward",), out=out)
+    assert rec["reward"] is out["reward"] and set(rec) == {"reward"}
+    for k in ("reward", "data_buf", "obs", "metrics", "mec_q"):
+        assert torch.equal(a.tensors[k], b.tensors[k]), k
+    with pytest.raises(ValueError):
+        b.step_many(pol[:, :, :, :1], pt, ngt)
+    with pytest.raises(ValueError):
+        b.step_many(pol, pt, ngt, record=("rewards",))
+    with pytest.raises(ValueError):
+        b.step_many(np.zeros((0, E, 2, V), np.float32), pt, ngt)
+    import ctypes as C
+    from ris_vec_marl_amd import _native as N
+    lib = N.load()
+    act = torch.zeros(T, E, 2, V, device="cuda:0")
+    args = (C.byref(b._cstate), C.byref(b._p()), T, act.data_ptr(), torch.as_tensor(pt).cuda().data_ptr(),
+            torch.as_tensor(ngt).cuda().data_ptr(), None, 0, 0)
+    assert lib.risvec_step_fused_multi(*args, N.STEP_STEER, None, None) == N.ERR_ARG
+    assert lib.risvec_step_fused_multi(*args[:2], 0, *args[3:], 0, None, None) == N.ERR_ARG

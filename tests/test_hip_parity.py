@@ -411,6 +411,8 @@ def test_step_golden(V, which):
     floor[:, 5] = 4e-7 * d_scale / scale[:, 5]
     floor[:, 12] = 4e-7 * d_scale / scale[:, 12]
     floor[:, 0] = 4e-7 * p.w_d * d_scale / scale[:, 0]
+    # edge compute delay = off * 1000 * Cpb / f_edge: `off` carries the (B - data_p) cancellation floor 4e-7 B (kbit)
+    floor[:, 7] = 4e-7 * np.maximum(g["data_buf0"], 1.0).mean(axis=1) * 1000 * p.cycles_per_bit / p.f_edge_max / scale[:, 7]
     assert ((rel <= RT + floor) | ~env_ok[:, None]).all(), np.argwhere((rel > RT + floor) & env_ok[:, None])[:5]
     record("step metrics rel err above floor", np.max(np.where(env_ok[:, None], rel - floor, 0.0)))
     # last_power_W = [E_tx ; E_loc] / time_fast; E_tx = p t_tx inherits t_tx's off/thr floor (1e-6 W absolute)
