@@ -60,6 +60,7 @@ enum {
     RISVEC_STEP_OBS = 8,            /* write obs[E,V,5] (marl_train_bcd.py:819-827)        */
     RISVEC_STEP_REUSE_COLSUM = 16,  /* risvec_step_fused_bcd: c_col is current, skip its rebuild */
     RISVEC_STEP_REUSE_SSUM = 32,    /* risvec_step_fused_bcd: s_sum is current (see RISVEC_BCD_REUSE_SSUM) */
+    RISVEC_STEP_REUSE_IDX = 128,    /* risvec_step_fused_bcd: theta_idx is current (see RISVEC_BCD_REUSE_IDX) */
     RISVEC_STEP_STEER = 64          /* risvec_step_fused: h_r is the steering vector risvec_geometry wrote
                                        (phases_R_i[v,m] = z_v^m, z_v = exp(-j pi angle_v), ENV:249-253): do not
                                        read it; evaluate sum_m theta_m b_m z^m by Horner in float64 from
@@ -70,8 +71,11 @@ enum {
 /* risvec_bcd flags */
 enum {
     RISVEC_BCD_REUSE_COLSUM = 1,   /* caller guarantees c_col matches h_r and b */
-    RISVEC_BCD_REUSE_SSUM = 2      /* caller guarantees theta and c_col are unchanged since the last sweep
+    RISVEC_BCD_REUSE_SSUM = 2,     /* caller guarantees theta and c_col are unchanged since the last sweep
                                       wrote s_sum: start from it instead of re-summing theta.c */
+    RISVEC_BCD_REUSE_IDX = 4       /* caller guarantees theta is unchanged since the last sweep wrote theta_idx (the
+                                      candidate index of every element): control_bit = 3 then takes the indexed sweep,
+                                      which never reads theta (about half the instructions per coordinate) */
 };
 
 /* Physics / geometry parameters: the attributes of `Environ` that the driver sets
@@ -161,6 +165,11 @@ typedef struct RisVecState {
     /* steering base z[e,v] = exp(-j pi angle_R[e,v]) in float64 (h_r[e,v,m] = z^m); written by risvec_geometry
        when non-NULL, read by risvec_step_fused with RISVEC_STEP_STEER */
     double *z_r;            /* [E,V]   c128 (may be NULL)                                 */
+    /* BCD cache: candidate index of every theta element as the last sweep left it (8 = the integer 0 of
+       ENV:211, 220), one byte each, in 8-byte words per (64-env slab, 8-element tile, env): word of
+       (e, m) at ((e/64 * ceil(M/8) + m/8) * 64 + e%64) * 8, byte m%8.  ceil(E/64)*64*ceil(M/8)*8 bytes;
+       written by every control_bit = 3 sweep, read with RISVEC_BCD_REUSE_IDX (may be NULL) */
+    uint8_t *theta_idx;
 } RisVecState;
 
 /* Parameters of the single-agent (SARL) environment variant,

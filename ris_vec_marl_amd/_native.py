@@ -23,7 +23,8 @@ CH_FREE, CH_3GPP_UMI, CH_3GPP_UMA, CH_OTHER = range(4)
 STEP_METRICS, STEP_POWER_W, STEP_POLICY_ACTION, STEP_OBS, STEP_REUSE_COLSUM = 1, 2, 4, 8, 16
 STEP_REUSE_SSUM = 32
 STEP_STEER = 64
-BCD_REUSE_COLSUM, BCD_REUSE_SSUM = 1, 2
+STEP_REUSE_IDX = 128
+BCD_REUSE_COLSUM, BCD_REUSE_SSUM, BCD_REUSE_IDX = 1, 2, 4
 
 METRIC_NAMES = (
     "global_reward", "last_off_kbit_sum", "last_local_kbit_sum", "last_mec_queue_cycles",
@@ -70,6 +71,7 @@ class RisVecState(C.Structure):
         ("data_buf", _FP), ("mec_q", _FP),
         ("rate", _FP), ("data_t", _FP), ("data_p", _FP), ("reward", _FP), ("over_power", _FP),
         ("obs", _FP), ("metrics", _FP), ("power_w", _FP), ("c_col", _FP), ("s_sum", _FP), ("over_data", _FP), ("z_r", _FP),
+        ("theta_idx", _FP),
     ]
 
 

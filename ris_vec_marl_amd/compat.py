@@ -141,7 +141,7 @@ class Environ(ParamAttrs):
     def elements_phase_shift_complex(self, value) -> None:
         z = np.asarray(value, dtype=np.complex128).reshape(self.M)
         self._upload("theta", np.stack([z.real, z.imag], -1))
-        self._vec._ssum_sweeps = 0            # theta changed: the cached sum theta.c is stale
+        self._vec._theta_changed()            # the cached sum theta.c and the candidate indices are stale
 
     @property
     def phases_R_i(self) -> np.ndarray:

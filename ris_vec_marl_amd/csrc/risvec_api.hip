@@ -74,7 +74,7 @@ int check_step(const char* fn, const RisVecState* s, const float* action, const 
     if (flags & RISVEC_STEP_OBS) REQ_PTR(s->obs, "state.obs");
     if (flags & RISVEC_STEP_POWER_W) REQ_PTR(s->power_w, "state.power_w");
     if (flags & ~(uint32_t)(RISVEC_STEP_METRICS | RISVEC_STEP_POWER_W | RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS |
-                            RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_STEER))
+                            RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX | RISVEC_STEP_STEER))
         return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
     if (flags & RISVEC_STEP_STEER) {
         if (!fused) return fail(RISVEC_ERR_ARG, "%s: RISVEC_STEP_STEER needs the fused entry points", fn);
@@ -216,12 +216,16 @@ int risvec_bcd(const RisVecState* s, const RisVecParams* p, int32_t* idx_out, ui
     REQ_PTR(s->c_col, "state.c_col");
     OPT_PTR(idx_out, "idx_out");
     OPT_PTR(s->s_sum, "state.s_sum");
-    if (flags & ~(uint32_t)(RISVEC_BCD_REUSE_COLSUM | RISVEC_BCD_REUSE_SSUM))
+    OPT_PTR(s->theta_idx, "state.theta_idx");
+    if (flags & ~(uint32_t)(RISVEC_BCD_REUSE_COLSUM | RISVEC_BCD_REUSE_SSUM | RISVEC_BCD_REUSE_IDX))
         return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
     if ((flags & RISVEC_BCD_REUSE_SSUM) && !s->s_sum)
         return fail(RISVEC_ERR_ARG, "%s: RISVEC_BCD_REUSE_SSUM needs state.s_sum", fn);
+    if ((flags & RISVEC_BCD_REUSE_IDX) && !s->theta_idx)
+        return fail(RISVEC_ERR_ARG, "%s: RISVEC_BCD_REUSE_IDX needs state.theta_idx", fn);
     return finish(fn, risvec::launch_bcd(*s, *p, idx_out, (flags & RISVEC_BCD_REUSE_COLSUM) != 0,
-                                         (flags & RISVEC_BCD_REUSE_SSUM) != 0, (hipStream_t)stream));
+                                         (flags & RISVEC_BCD_REUSE_SSUM) != 0, (flags & RISVEC_BCD_REUSE_IDX) != 0,
+                                         (hipStream_t)stream));
 }
 
 int risvec_set_phase(const RisVecState* s, const float* angle, risvec_stream_t stream) {
@@ -278,7 +282,7 @@ int risvec_step_fused_multi(const RisVecState* s, const RisVecParams* p, int32_t
     if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     if (int rc = check_common(fn, s, p)) return rc;
     if (n_steps < 1 || n_steps > (1 << 20)) return fail(RISVEC_ERR_ARG, "%s: n_steps=%d outside [1, 2^20]", fn, n_steps);
-    if (flags & (RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_STEER))
+    if (flags & (RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX | RISVEC_STEP_STEER))
         return fail(RISVEC_ERR_ARG, "%s: the BCD / steering flags (0x%x) are not accepted by the multi-step launch", fn, flags);
     if (int rc = check_step(fn, s, actions, partner, n_groups, arrivals, flags, true)) return rc;
     if (traj) { OPT_PTR(traj->reward, "traj.reward"); OPT_PTR(traj->obs, "traj.obs"); OPT_PTR(traj->metrics, "traj.metrics"); }
@@ -336,6 +340,9 @@ int risvec_step_fused_bcd(const RisVecState* s, const RisVecParams* p, const flo
     if (int rc = check_common(fn, s, p)) return rc;
     if (int rc = check_step(fn, s, action, partner, n_groups, arrivals, flags, true)) return rc;
     REQ_PTR(s->c_col, "state.c_col");
+    OPT_PTR(s->theta_idx, "state.theta_idx");
+    if ((flags & RISVEC_STEP_REUSE_IDX) && !s->theta_idx)
+        return fail(RISVEC_ERR_ARG, "%s: RISVEC_STEP_REUSE_IDX needs state.theta_idx", fn);
     return finish(fn, risvec::launch_step_fused_bcd(*s, *p, action, partner, n_groups, arrivals, seed,
                                                     counter, flags, (hipStream_t)stream));
 }

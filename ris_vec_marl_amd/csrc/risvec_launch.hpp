@@ -32,7 +32,7 @@ hipError_t launch_data_rate(const RisVecState& s, const RisVecParams& p, const f
 
 hipError_t launch_colsum(const RisVecState& s, hipStream_t st);
 hipError_t launch_bcd(const RisVecState& s, const RisVecParams& p, int32_t* idx_out, bool reuse_colsum,
-                      bool reuse_s, hipStream_t st);
+                      bool reuse_s, bool reuse_idx, hipStream_t st);
 hipError_t launch_step_fused_bcd(const RisVecState& s, const RisVecParams& p, const float* action,
                                  const int32_t* partner, const int32_t* n_groups,
                                  const int32_t* arrivals, uint64_t seed, uint32_t counter,

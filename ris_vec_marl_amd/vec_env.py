@@ -95,6 +95,7 @@ class VecEnviron(ParamAttrs):
         self._steer_valid = False      # h_r is the steering vector compute_parms wrote, z_r its base
         self._ssum_sweeps = 0          # >0: s_sum = sum theta.c of the CURRENT theta, left by that many
                                        # consecutive sweeps (0 = unknown; refreshed every 64 sweeps)
+        self._idx_valid = False        # theta_idx = candidate index of every CURRENT theta element (left by a sweep)
         self._cstate: Optional[N.RisVecState] = None
         self._cparams: Optional[N.RisVecParams] = None
         self._cparams_version = -1
@@ -138,6 +139,8 @@ class VecEnviron(ParamAttrs):
         t["c_col"] = z((E + 63) // 64, M, 64, 2, dt=torch.float64)
         t["s_sum"] = z(E, 2, dt=torch.float64)         # sum_m theta_m c_m left by the last sweep
         t["z_r"] = z(E, V, 2, dt=torch.float64)        # steering base exp(-j pi angle) per vehicle: h_r[e,v,m] = z^m
+        # candidate index of every theta element as the last BCD sweep left it: [ceil(E/64), ceil(M/8), 64, 8] bytes
+        t["theta_idx"] = z((E + 63) // 64, (M + 7) // 8, 64, 8, dt=torch.uint8)
         s = N.RisVecState()
         s.abi_version = N.ABI_VERSION
         s.struct_bytes = C.sizeof(N.RisVecState)
@@ -145,7 +148,7 @@ class VecEnviron(ParamAttrs):
         s.env_offset = self.env_offset
         for k in ("pos", "dir", "vel", "dist_r", "ang_r", "pl", "h_r", "theta", "b", "gain", "data_buf",
                   "mec_q", "rate", "data_t", "data_p", "reward", "over_power", "obs", "metrics", "power_w", "c_col",
-                  "s_sum", "over_data", "z_r"):
+                  "s_sum", "over_data", "z_r", "theta_idx"):
             setattr(s, k, t[k].data_ptr())
         s.h_d = None
         self._cstate = s
@@ -243,7 +246,7 @@ class VecEnviron(ParamAttrs):
         N.check(N.load().risvec_geometry(C.byref(self._cstate), C.byref(self._p()), self._stream()))
         self._colsum_valid = True
         self._steer_valid = True       # h_r[e,v,m] = z_r[e,v]^m from here on
-        self._ssum_sweeps = 0
+        self._ssum_sweeps = 0          # c changed: the cached sum is stale (the candidate indices are not)
 
     def rebuild_colsum(self) -> None:
         """Recompute the BCD cache c_col[e,m] = (sum_v h_r[e,v,m]) b[m] (float64).  compute_parms()
@@ -262,21 +265,35 @@ class VecEnviron(ParamAttrs):
 
     def invalidate_colsum(self) -> None:
         """Tell the env that h_r or theta was modified behind its back (a direct write to
-        `tensors[...]`): the next BCD rebuilds c_col and re-sums theta.c."""
+        `tensors[...]`): the next BCD rebuilds c_col, re-sums theta.c and re-derives the candidate indices."""
         self._colsum_valid = False
+        self._theta_changed()
+
+    def invalidate_theta(self) -> None:
+        """Tell the env that `tensors["theta"]` was written directly: the next BCD sweep re-sums theta.c and
+        re-derives the candidate indices (the phase setters and the sweeps themselves keep track on their own)."""
+        self._theta_changed()
+
+    def _theta_changed(self) -> None:
+        """theta was written by something other than a BCD sweep: its cached sum and candidate indices are stale."""
         self._ssum_sweeps = 0
+        self._idx_valid = False
 
     def _bcd_flags(self, reuse_colsum: Optional[bool], step: bool) -> int:
         reuse_c = self._colsum_valid if reuse_colsum is None else bool(reuse_colsum)
         reuse_s = reuse_c and 0 < self._ssum_sweeps < 64
+        reuse_i = self._idx_valid and self.control_bit == 3
         if step:
-            return (N.STEP_REUSE_COLSUM if reuse_c else 0) | (N.STEP_REUSE_SSUM if reuse_s else 0)
-        return (N.BCD_REUSE_COLSUM if reuse_c else 0) | (N.BCD_REUSE_SSUM if reuse_s else 0)
+            return ((N.STEP_REUSE_COLSUM if reuse_c else 0) | (N.STEP_REUSE_SSUM if reuse_s else 0)
+                    | (N.STEP_REUSE_IDX if reuse_i else 0))
+        return ((N.BCD_REUSE_COLSUM if reuse_c else 0) | (N.BCD_REUSE_SSUM if reuse_s else 0)
+                | (N.BCD_REUSE_IDX if reuse_i else 0))
 
     def _bcd_done(self, flags: int, step: bool) -> None:
         reused_s = bool(flags & (N.STEP_REUSE_SSUM if step else N.BCD_REUSE_SSUM))
         self._colsum_valid = True
         self._ssum_sweeps = self._ssum_sweeps + 1 if reused_s else 1
+        self._idx_valid = self.control_bit == 3        # every 2^b = 8 sweep leaves the indices of what it stored
 
     def optimize_phase_shift(self, return_idx: bool = False, reuse_colsum: Optional[bool] = None):
         """Environment.py:208-220 (one BCD sweep, objective of :222-231).  The column sums the
@@ -315,7 +332,7 @@ class VecEnviron(ParamAttrs):
         self._ensure_device()
         a = self._arg(action_phase, torch.float32, (self.n_envs, self.M), "action_phase")
         N.check(N.load().risvec_set_phase(C.byref(self._cstate), _dev_ptr(a), self._stream()))
-        self._ssum_sweeps = 0
+        self._theta_changed()
 
     def Random_phase(self, idx=None) -> None:
         """Environment.py:203-206; idx [E,M] int32 indices into possible_angles (optional)."""
@@ -324,7 +341,7 @@ class VecEnviron(ParamAttrs):
         self._chan += 1
         N.check(N.load().risvec_random_phase(C.byref(self._cstate), _dev_ptr(i), self.seed, self._chan,
                                              self._stream()))
-        self._ssum_sweeps = 0
+        self._theta_changed()
 
     def data_rate(self, p_off, partner, n_groups) -> torch.Tensor:
         """Environment.py:331-372 on the cached gains: p_off [E,V] offload power in W -> rate [E,V]."""
@@ -483,7 +500,7 @@ class VecEnviron(ParamAttrs):
                                           _dev_ptr(ar), self.seed, self._steps, N.STEP_OBS if obs else 0,
                                           self._stream()))
         if ph is not None:
-            self._ssum_sweeps = 0
+            self._theta_changed()
         self._steps += 1
         self._obs_stale = False        # sarl_observe assembles its own observation from the state tensors
         t = self._t
@@ -592,7 +609,7 @@ class VecEnviron(ParamAttrs):
             if k in sd:                # power_w joined the checkpoint in round 2
                 t[k].copy_(sd[k])
         self._colsum_valid = False
-        self._ssum_sweeps = 0
+        self._theta_changed()
         self._epoch, self._moves, self._steps, self._chan = c["epoch"], c["moves"], c["steps"], c["chan"]
         self._steer_valid = bool(c.get("steer_valid", False))      # z_r travels with h_r
         self._obs_stale = bool(c.get("obs_stale", self._steps == 0))

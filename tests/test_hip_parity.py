@@ -841,7 +841,7 @@ def test_colsum_cache(V, M):
     # a sweep that reuses the cache == a sweep that rebuilds it, bit for bit
     env.Random_phase(); th0 = t["theta"].clone()
     i1 = cpu(env.optimize_phase_shift(return_idx=True, reuse_colsum=True)).copy(); th1 = cpu(t["theta"]).copy()
-    t["theta"].copy_(th0)
+    t["theta"].copy_(th0); env.invalidate_theta()           # a direct write to theta must be announced
     i2 = cpu(env.optimize_phase_shift(return_idx=True, reuse_colsum=False))
     assert np.array_equal(i1, i2) and np.array_equal(th1, cpu(t["theta"]))
     # and matches the oracle on the same float32 inputs
