@@ -313,13 +313,18 @@ class Case:
             partner, n_groups = grouper.group(action[:, 0, :].contiguous(), 0)     # state views: stable pointers
         p_off01 = action[:, 0, :].contiguous()
         marshal = store = None
+        direct = False
         if opts.replay:
             from ris_vec_marl_amd import VecReplayBuffer, marshal_actions
             power_raw = torch.from_numpy(rng.uniform(-1, 1, (E, V, 2)).astype(np.float32)).to(device)
             probs = torch.from_numpy(rng.dirichlet(np.ones(V), (E, V)).astype(np.float32)).to(device)
             a_store = torch.empty(E, V * (V + 2), device=device)
             floor = float(env.cpu_share_floor)
-            marshal = lambda: marshal_actions(power_raw, probs, floor, out=(action, p_off01, a_store))   # noqa: E731
+            # Default: NO marshalling launch -- the env, the grouping and the ring read the policy outputs in place
+            # (RISVEC_STEP_POLICY_ACTION, risvec_noma_group_raw, risvec_replay_store_policy).  --marshal keeps the
+            # round-1 form (one more launch writing action_env / p_off01 / action_store).
+            direct = not getattr(opts, "marshal", False) and not opts.policy and mode != "sarl"
+            marshal = None if direct else (lambda: marshal_actions(power_raw, probs, floor, out=(action, p_off01, a_store)))   # noqa: E731
             if opts.policy:
                 from ris_vec_marl_amd import BatchedPolicy
                 policy = BatchedPolicy(V, 5, 512, 256, device=device, seed=rank, env_offset=start)
@@ -327,11 +332,17 @@ class Case:
                 def marshal():                 # policy forward + sample + marshal; outputs land in the bound tensors
                     policy.choose_action(env.tensors["obs"], grouper.mask, cpu_share_floor=floor, want_onehot=False,
                                          out=(action, p_off01, a_store))
-            marshal()
+            if marshal is not None:
+                marshal()
             replay = VecReplayBuffer(16 * E, 5, V + 2, V, device=device)
-            store = replay.bind_store(None, a_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"],
-                                      grouper.mask)
-        group = grouper.bind_group(p_off01) if grouper is not None else None
+            store = replay.bind_store(None, None if direct else a_store, env.tensors["metrics"], env.tensors["reward"],
+                                      env.tensors["obs"], grouper.mask, policy_out=(power_raw, probs) if direct else None)
+        if grouper is None:
+            group = None
+        elif direct:
+            group = grouper.bind_group(power_raw=power_raw)
+        else:
+            group = grouper.bind_group(p_off01)
         if mode == "sarl":
             from ris_vec_marl_amd.sarl import SarlParams
             phase = torch.from_numpy(rng.uniform(0, 2 * np.pi, (E, M)).astype(np.float32)).to(device)
@@ -347,8 +358,8 @@ class Case:
             launch = env.bind_step_many(actions, partner, n_groups, None, metrics=full, obs=full, out=traj)
             self.multi = T
         else:
-            launch = env.bind_step(action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full,
-                                   power_w=opts.meter, obs=full, steer=opts.steer and fused)
+            launch = env.bind_step(power_raw if direct else action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full,
+                                   power_w=opts.meter, obs=full, steer=opts.steer and fused, policy_action=direct)
         self.episode_len = 100
         meter = meter_add = None
         if opts.meter:
@@ -436,7 +447,7 @@ class Case:
 
 
 class _Opts:
-    lean = steer = noma = replay = policy = meter = False
+    lean = steer = noma = replay = policy = meter = marshal = False
     multi = 0
 
     def __init__(self, **kw):
@@ -562,6 +573,9 @@ def main() -> None:
     ap.add_argument("--meter", action="store_true",
                     help="f4: add every step's metrics / rewards / powers to the per-env episode accumulators "
                          "(EpisodeMeter) and reduce the episode scalars over the envs every 100 steps")
+    ap.add_argument("--marshal", action="store_true",
+                    help="with --replay: keep the separate marshalling launch (action_env / p_off01 / action_store written "
+                         "to HBM first) instead of letting the three consumers read the policy outputs in place")
     ap.add_argument("--multi", type=int, default=0, metavar="T",
                     help="advance the envs by T steps per launch (risvec_step_fused_multi: actions [T,E,2,V], per-step "
                          "reward / obs / metrics recorded) -- the launch shape for batches whose single step is shorter "
@@ -668,8 +682,9 @@ def main() -> None:
                    "envs_per_gpu": E, "n_veh": V, "n_ris": M, "mode": args.mode, "allgather": gather_note,
                    "noma_grouping": ("device, every step, 100-step episodes (config.yaml pairing keys)"
                                      if args.noma else "synthetic fixed groups"),
-                   "replay": ("marshal + HBM replay ring store every step (%d B per transition)"
-                              % (4 * (10 * V + V * (V + 2) + V + 1 + V * V) + 1) if args.replay else "off"),
+                   "replay": ("%sHBM replay ring store every step (%d B per transition)"
+                              % ("marshal launch + " if (args.marshal or args.policy) else "policy outputs read in place, ",
+                                 4 * (10 * V + V * (V + 2) + V + 1 + V * V) + 1) if args.replay else "off"),
                    "policy": "BatchedPolicy 8x(5-512-256), every step" if args.policy else "synthetic outputs",
                    "steering_form": bool(args.steer and fused),
                    "launch": ("one launch per step" if args.multi <= 1 else

@@ -415,6 +415,14 @@ int risvec_noma_group(const RisVecNomaState *ns, const RisVecNomaParams *np, con
                       int32_t i_step, const float *u_unstick, uint64_t seed, uint32_t counter,
                       int32_t *info_out, risvec_stream_t stream);
 
+/* risvec_noma_group reading the pairing power straight from the SAC power head: power_raw [E,N,2] in [-1,1], of which
+ * component 0 is mapped as risvec_marshal_actions maps it (TRAIN:1391-1396, bit for bit) -- no marshalling launch. */
+int risvec_noma_group_raw(const RisVecNomaState *ns, const RisVecNomaParams *np, const float *gain,
+                          const double *gdb12, const float *power_raw, int32_t use_mask, int32_t K_back,
+                          const double *tau_back, const float *prev_global, int32_t prev_global_stride,
+                          int32_t i_step, const float *u_unstick, uint64_t seed, uint32_t counter,
+                          int32_t *info_out, risvec_stream_t stream);
+
 /* Apply the deferred frozen steps to hist / streak (pair_hist_decay = np->pair_hist_decay). */
 int risvec_noma_flush(const RisVecNomaState *ns, const RisVecNomaParams *np, risvec_stream_t stream);
 
@@ -446,6 +454,16 @@ int risvec_replay_store(const RisVecReplay *rb, int64_t mem_cntr, int32_t n, con
                         const float *reward_g, int32_t reward_g_stride, const float *reward_l, const float *state_,
                         const uint8_t *done, int32_t done_all, const uint8_t *mask, float *state_carry,
                         risvec_stream_t stream);
+
+/* risvec_replay_store with the action row built in the store kernel from the policy outputs -- power_raw [n,A,2],
+ * probs [n,A,A]: per agent [probs_i with zero diagonal | raw power_i], exactly the action_store row of
+ * risvec_marshal_actions (TRAIN:1386-1390, 1776-1784) -- so a rollout step needs no marshalling launch: the env
+ * takes power_raw with RISVEC_STEP_POLICY_ACTION, the grouping takes it through risvec_noma_group_raw.
+ * Needs n_actions = n_agents + 2. */
+int risvec_replay_store_policy(const RisVecReplay *rb, int64_t mem_cntr, int32_t n, const float *state,
+                               const float *power_raw, const float *probs, const float *reward_g,
+                               int32_t reward_g_stride, const float *reward_l, const float *state_, const uint8_t *done,
+                               int32_t done_all, const uint8_t *mask, float *state_carry, risvec_stream_t stream);
 
 /* sample_buffer (BUF:27-37): rows idx[b] (int64, each < max_mem = min(mem_cntr, mem_size)) or, with
  * idx NULL, Philox(seed; b, 0, counter, site 8) -> floor(x * max_mem / 2^32); outputs [batch, ...] in the

@@ -157,9 +157,14 @@ _PROTOS = {
     "risvec_noma_group": (C.c_int, [C.POINTER(RisVecNomaState), C.POINTER(RisVecNomaParams), _FP, _FP, _FP,
                                     C.c_int32, C.c_int32, _FP, _FP, C.c_int32, C.c_int32, _FP,
                                     C.c_uint64, C.c_uint32, _FP, _FP]),
+    "risvec_noma_group_raw": (C.c_int, [C.POINTER(RisVecNomaState), C.POINTER(RisVecNomaParams), _FP, _FP, _FP,
+                                        C.c_int32, C.c_int32, _FP, _FP, C.c_int32, C.c_int32, _FP,
+                                        C.c_uint64, C.c_uint32, _FP, _FP]),
     "risvec_noma_flush": (C.c_int, [C.POINTER(RisVecNomaState), C.POINTER(RisVecNomaParams), _FP]),
     "risvec_replay_store": (C.c_int, [C.POINTER(RisVecReplay), C.c_int64, C.c_int32, _FP, _FP, _FP, C.c_int32, _FP,
                                       _FP, _FP, C.c_int32, _FP, _FP, _FP]),
+    "risvec_replay_store_policy": (C.c_int, [C.POINTER(RisVecReplay), C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, C.c_int32, _FP,
+                                             _FP, _FP, C.c_int32, _FP, _FP, _FP]),
     "risvec_replay_sample": (C.c_int, [C.POINTER(RisVecReplay), C.c_int64, C.c_int32, _FP, C.c_uint64, C.c_uint32,
                                        _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "risvec_marshal_actions": (C.c_int, [C.c_int32, C.c_int32, _FP, _FP, C.c_float, _FP, _FP, _FP, _FP]),

@@ -46,6 +46,7 @@ struct NomaArgs {
     const float* gain;
     const double* gdb12;
     const float* p01;
+    int p01_raw;                 // p01 is the raw SAC power head [E,N,2] in [-1,1]: apply TRAIN:1391-1396 when read
     int use_mask;
     int K_back;
     const double* tau_back;
@@ -358,7 +359,16 @@ k_noma_group(NomaArgs A) {
             const double g = (double)A.gain[(long long)env * N + lane];
             s_lin[lane] = g;
             s_g[lane] = A.gdb12 ? A.gdb12[(long long)env * N + lane] : 10.0 * log10(fmax(g, 1e-12));
-            s_p[lane] = A.p01 ? (double)A.p01[(long long)env * N + lane] : 0.0;
+            float p = 0.0f;
+            if (A.p01) {
+                if (A.p01_raw) {                               // TRAIN:1391-1396, as risvec_marshal_actions computes it
+                    const float a0 = A.p01[((long long)env * N + lane) * 2];
+                    p = (fminf(fmaxf(a0, -0.999f), 0.999f) + 1.0f) / 2.0f;
+                } else {
+                    p = A.p01[(long long)env * N + lane];
+                }
+            }
+            s_p[lane] = (double)p;
             s_part[lane] = had_groups ? A.ns.partner[(long long)env * N + lane] : -1;
         }
         __syncthreads();
@@ -702,11 +712,11 @@ hipError_t launch_noma_flush(const RisVecNomaState& ns, float decay, hipStream_t
 }
 
 hipError_t launch_noma_group(const RisVecNomaState& ns, const RisVecNomaParams& p, const float* gain,
-                             const double* gdb12, const float* p01, int use_mask, int K_back,
+                             const double* gdb12, const float* p01, int p01_raw, int use_mask, int K_back,
                              const double* tau_back, const float* prev_global, int prev_stride, int i_step,
                              const float* u_unstick, uint64_t seed, uint32_t counter, int32_t* info_out,
                              hipStream_t st) {
-    NomaArgs a{ns, p, gain, gdb12, p01, use_mask, K_back, tau_back, prev_global, prev_stride, i_step,
+    NomaArgs a{ns, p, gain, gdb12, p01, p01_raw, use_mask, K_back, tau_back, prev_global, prev_stride, i_step,
                u_unstick, seed, counter, info_out};
     const int epw = ns.n_veh <= 8 ? EnvsPerWave<8>::value : EnvsPerWave<16>::value;
     long long waves = ((long long)ns.n_envs + epw - 1) / epw;

@@ -18,7 +18,8 @@ struct StoreArgs {
     RisVecReplay rb;
     long long cursor;            // mem_cntr before this call
     int n;
-    const float* state; const float* action; const float* reward_g; int rg_stride; const float* reward_l;
+    const float* state; const float* action; const float* power_raw; const float* probs;   // action == nullptr: row built from the policy outputs
+    const float* reward_g; int rg_stride; const float* reward_l;
     const float* state_; const uint8_t* done; int done_all; const uint8_t* mask;
     float* carry;                // optional [n, input_shape*n_agents]: receives a copy of state_
 };
@@ -65,7 +66,22 @@ k_replay_store(StoreArgs A) {
             *reinterpret_cast<F*>(rb.state_memory + dest(w, S)) = *reinterpret_cast<const F*>(A.state + w);
         } else if (w < b1) {
             const long long g = w - b0;
-            *reinterpret_cast<F*>(rb.action_memory + dest(g, Ac)) = *reinterpret_cast<const F*>(A.action + g);
+            if (A.action) {
+                *reinterpret_cast<F*>(rb.action_memory + dest(g, Ac)) = *reinterpret_cast<const F*>(A.action + g);
+            } else {
+                // the row risvec_marshal_actions would have built (TRAIN:1386-1390, 1776-1784), straight from the policy
+                // outputs: per agent [probs_i with zero diagonal | raw power_i]
+                float o[VEC];
+                const unsigned W = (unsigned)rb.n_agents + 2, Vn = (unsigned)rb.n_agents;
+                // one 32-bit division per lane (n * Ac < 2^32 is checked by the launcher), then walk the VEC words
+                unsigned ev = (unsigned)g / W, k = (unsigned)g - ev * W, v = ev % Vn;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    o[c] = k < Vn ? (k == v ? 0.0f : A.probs[(size_t)ev * Vn + k]) : A.power_raw[(size_t)ev * 2 + (k - Vn)];
+                    if (++k == W) { k = 0; ++ev; v = v + 1 == Vn ? 0 : v + 1; }
+                }
+                *reinterpret_cast<F*>(rb.action_memory + dest(g, Ac)) = *reinterpret_cast<const F*>(o);
+            }
         } else if (w < b2) {
             const long long g = w - b1;
             *reinterpret_cast<F*>(rb.reward_local_memory + dest(g, L)) = *reinterpret_cast<const F*>(A.reward_l + g);
@@ -203,12 +219,13 @@ k_marshal_pairs(int E, int V, const float* power_raw, const float* probs, float 
 }  // namespace
 
 hipError_t launch_replay_store(const RisVecReplay& rb, long long cursor, int n, const float* state, const float* action,
-                               const float* reward_g, int rg_stride, const float* reward_l, const float* state_,
+                               const float* power_raw, const float* probs, const float* reward_g, int rg_stride, const float* reward_l, const float* state_,
                                const uint8_t* done, int done_all, const uint8_t* mask, float* carry, hipStream_t st) {
     const long long S = (long long)rb.input_shape * rb.n_agents, Ac = (long long)rb.n_actions * rb.n_agents;
     const long long L = rb.n_agents, M = L * L;
     const long long words = (long long)n * (2 * S + Ac + L + M);
-    StoreArgs a{rb, cursor, n, state, action, reward_g, rg_stride, reward_l, state_, done, done_all, mask, carry};
+    if (!action && (long long)n * Ac >= (1LL << 32)) return hipErrorInvalidValue;   // 32-bit word index in the policy-output form
+    StoreArgs a{rb, cursor, n, state, action, power_raw, probs, reward_g, rg_stride, reward_l, state_, done, done_all, mask, carry};
     const bool vec = S % 4 == 0 && Ac % 4 == 0 && L % 4 == 0;      // then M = L*L is too
     const long long threads = (vec ? words / 4 : words) + 2LL * n;
     const dim3 grid((unsigned)((threads + kBlock - 1) / kBlock));

@@ -408,11 +408,11 @@ static int check_noma_state(const char* fn, const RisVecNomaState* ns) {
     return RISVEC_OK;
 }
 
-int risvec_noma_group(const RisVecNomaState* ns, const RisVecNomaParams* np, const float* gain, const double* gdb12,
-                      const float* p_off01, int32_t use_mask, int32_t K_back, const double* tau_back,
-                      const float* prev_global, int32_t prev_global_stride, int32_t i_step, const float* u_unstick,
-                      uint64_t seed, uint32_t counter, int32_t* info_out, risvec_stream_t stream) {
-    const char* fn = "risvec_noma_group";
+static int noma_group_impl(const char* fn, const RisVecNomaState* ns, const RisVecNomaParams* np, const float* gain,
+                           const double* gdb12, const float* p_off01, int p01_raw, int32_t use_mask, int32_t K_back,
+                           const double* tau_back, const float* prev_global, int32_t prev_global_stride, int32_t i_step,
+                           const float* u_unstick, uint64_t seed, uint32_t counter, int32_t* info_out,
+                           risvec_stream_t stream) {
     if (int rc = check_noma(fn, ns)) return rc;
     if (!np) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     REQ_PTR(gain, "gain"); OPT_PTR(gdb12, "gdb12"); OPT_PTR(p_off01, "p_off01"); REQ_PTR(tau_back, "tau_back");
@@ -427,9 +427,25 @@ int risvec_noma_group(const RisVecNomaState* ns, const RisVecNomaParams* np, con
     if (K_back < 0) return fail(RISVEC_ERR_ARG, "%s: K_back=%d must be >= 0", fn, K_back);
     if (np->mwm_backoff_rounds < 0 || np->mwm_backoff_rounds > 64)
         return fail(RISVEC_ERR_ARG, "%s: mwm_backoff_rounds=%d outside [0,64]", fn, np->mwm_backoff_rounds);
-    return finish(fn, risvec::launch_noma_group(*ns, *np, gain, gdb12, p_off01, use_mask, K_back, tau_back,
+    return finish(fn, risvec::launch_noma_group(*ns, *np, gain, gdb12, p_off01, p01_raw, use_mask, K_back, tau_back,
                                                 prev_global, prev_global_stride, i_step, u_unstick, seed, counter,
                                                 info_out, (hipStream_t)stream));
+}
+
+int risvec_noma_group(const RisVecNomaState* ns, const RisVecNomaParams* np, const float* gain, const double* gdb12,
+                      const float* p_off01, int32_t use_mask, int32_t K_back, const double* tau_back,
+                      const float* prev_global, int32_t prev_global_stride, int32_t i_step, const float* u_unstick,
+                      uint64_t seed, uint32_t counter, int32_t* info_out, risvec_stream_t stream) {
+    return noma_group_impl("risvec_noma_group", ns, np, gain, gdb12, p_off01, 0, use_mask, K_back, tau_back, prev_global,
+                           prev_global_stride, i_step, u_unstick, seed, counter, info_out, stream);
+}
+
+int risvec_noma_group_raw(const RisVecNomaState* ns, const RisVecNomaParams* np, const float* gain, const double* gdb12,
+                          const float* power_raw, int32_t use_mask, int32_t K_back, const double* tau_back,
+                          const float* prev_global, int32_t prev_global_stride, int32_t i_step, const float* u_unstick,
+                          uint64_t seed, uint32_t counter, int32_t* info_out, risvec_stream_t stream) {
+    return noma_group_impl("risvec_noma_group_raw", ns, np, gain, gdb12, power_raw, 1, use_mask, K_back, tau_back,
+                           prev_global, prev_global_stride, i_step, u_unstick, seed, counter, info_out, stream);
 }
 
 int risvec_noma_flush(const RisVecNomaState* ns, const RisVecNomaParams* np, risvec_stream_t stream) {
@@ -457,25 +473,50 @@ static int check_replay(const char* fn, const RisVecReplay* rb) {
     return RISVEC_OK;
 }
 
-int risvec_replay_store(const RisVecReplay* rb, int64_t mem_cntr, int32_t n, const float* state, const float* action,
-                        const float* reward_g, int32_t reward_g_stride, const float* reward_l, const float* state_,
-                        const uint8_t* done, int32_t done_all, const uint8_t* mask, float* state_carry,
-                        risvec_stream_t stream) {
-    const char* fn = "risvec_replay_store";
+static int replay_store_impl(const char* fn, const RisVecReplay* rb, int64_t mem_cntr, int32_t n, const float* state,
+                             const float* action, const float* power_raw, const float* probs, const float* reward_g,
+                             int32_t reward_g_stride, const float* reward_l, const float* state_, const uint8_t* done,
+                             int32_t done_all, const uint8_t* mask, float* state_carry, risvec_stream_t stream) {
     if (int rc = check_replay(fn, rb)) return rc;
     if (n < 1 || n > rb->mem_size)
         return fail(RISVEC_ERR_SHAPE, "%s: n=%d outside [1, mem_size=%lld] (a batch may not overwrite itself)", fn, n,
                     (long long)rb->mem_size);
     if (mem_cntr < 0) return fail(RISVEC_ERR_ARG, "%s: mem_cntr=%lld must be >= 0", fn, (long long)mem_cntr);
     if (reward_g_stride < 1) return fail(RISVEC_ERR_ARG, "%s: reward_g_stride=%d must be >= 1", fn, reward_g_stride);
-    REQ_PTR(state, "state"); REQ_PTR(action, "action"); REQ_PTR(reward_l, "reward_l"); REQ_PTR(state_, "state_");
+    REQ_PTR(state, "state"); REQ_PTR(reward_l, "reward_l"); REQ_PTR(state_, "state_");
+    if (action) {
+        REQ_PTR(action, "action");
+    } else {
+        REQ_PTR(power_raw, "power_raw"); REQ_PTR(probs, "probs");
+        if (rb->n_actions != rb->n_agents + 2)
+            return fail(RISVEC_ERR_SHAPE, "%s: the policy-output form needs n_actions = n_agents + 2 (got %d, %d)", fn,
+                        rb->n_actions, rb->n_agents);
+    }
     OPT_PTR(state_carry, "state_carry"); OPT_PTR(mask, "mask");
     if (state_carry == state || state_carry == state_)
         return fail(RISVEC_ERR_ARG, "%s: state_carry must not alias state / state_ (other lanes are reading them)", fn);
     if (!reward_g || (reinterpret_cast<uintptr_t>(reward_g) & 3u))
         return fail(RISVEC_ERR_ARG, "%s: reward_g is NULL or not 4-byte aligned", fn);
-    return finish(fn, risvec::launch_replay_store(*rb, mem_cntr, n, state, action, reward_g, reward_g_stride, reward_l,
+    return finish(fn, risvec::launch_replay_store(*rb, mem_cntr, n, state, action, power_raw, probs, reward_g, reward_g_stride, reward_l,
                                                   state_, done, done_all, mask, state_carry, (hipStream_t)stream));
+}
+
+int risvec_replay_store(const RisVecReplay* rb, int64_t mem_cntr, int32_t n, const float* state, const float* action,
+                        const float* reward_g, int32_t reward_g_stride, const float* reward_l, const float* state_,
+                        const uint8_t* done, int32_t done_all, const uint8_t* mask, float* state_carry,
+                        risvec_stream_t stream) {
+    if (!action && rb && rb->mem_size >= 1 && rb->n_agents >= 1 && rb->state_memory)   // (a malformed rb is reported first)
+        return fail(RISVEC_ERR_ARG, "risvec_replay_store: action is NULL");
+    return replay_store_impl("risvec_replay_store", rb, mem_cntr, n, state, action, nullptr, nullptr, reward_g, reward_g_stride,
+                             reward_l, state_, done, done_all, mask, state_carry, stream);
+}
+
+int risvec_replay_store_policy(const RisVecReplay* rb, int64_t mem_cntr, int32_t n, const float* state,
+                               const float* power_raw, const float* probs, const float* reward_g, int32_t reward_g_stride,
+                               const float* reward_l, const float* state_, const uint8_t* done, int32_t done_all,
+                               const uint8_t* mask, float* state_carry, risvec_stream_t stream) {
+    return replay_store_impl("risvec_replay_store_policy", rb, mem_cntr, n, state, nullptr, power_raw, probs, reward_g,
+                             reward_g_stride, reward_l, state_, done, done_all, mask, state_carry, stream);
 }
 
 int risvec_replay_sample(const RisVecReplay* rb, int64_t max_mem, int32_t batch, const int64_t* idx, uint64_t seed,

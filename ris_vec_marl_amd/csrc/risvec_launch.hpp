@@ -46,14 +46,14 @@ hipError_t launch_noma_begin_episode(const RisVecNomaState& ns, hipStream_t st);
 hipError_t launch_noma_mask(const RisVecNomaState& ns, const float* gain, const double* gdb15, double q_now,
                             int K_now, hipStream_t st);
 hipError_t launch_noma_group(const RisVecNomaState& ns, const RisVecNomaParams& p, const float* gain,
-                             const double* gdb12, const float* p01, int use_mask, int K_back,
+                             const double* gdb12, const float* p01, int p01_raw, int use_mask, int K_back,
                              const double* tau_back, const float* prev_global, int prev_stride, int i_step,
                              const float* u_unstick, uint64_t seed, uint32_t counter, int32_t* info_out,
                              hipStream_t st);
 hipError_t launch_noma_flush(const RisVecNomaState& ns, float decay, hipStream_t st);
 
 hipError_t launch_replay_store(const RisVecReplay& rb, long long cursor, int n, const float* state, const float* action,
-                               const float* reward_g, int rg_stride, const float* reward_l, const float* state_,
+                               const float* power_raw, const float* probs, const float* reward_g, int rg_stride, const float* reward_l, const float* state_,
                                const uint8_t* done, int done_all, const uint8_t* mask, float* carry, hipStream_t st);
 hipError_t launch_replay_sample(const RisVecReplay& rb, long long max_mem, int batch, const int64_t* idx, uint64_t seed,
                                 uint32_t counter, float* states, float* actions, float* rewards_g, float* rewards_l,

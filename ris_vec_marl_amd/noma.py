@@ -227,11 +227,13 @@ class NomaGrouper:
 
     def group(self, p_off01: Optional[torch.Tensor], i_step: int, gain: Optional[torch.Tensor] = None,
               prev_global: Optional[torch.Tensor] = None, gdb12: Optional[torch.Tensor] = None,
-              gdb15: Optional[torch.Tensor] = None, u_unstick: Optional[torch.Tensor] = None
-              ) -> Tuple[torch.Tensor, torch.Tensor]:
+              gdb15: Optional[torch.Tensor] = None, u_unstick: Optional[torch.Tensor] = None,
+              power_raw: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """TRAIN:1401-1562 for every env -> (partner [E,N] int32, n_groups [E] int32), the batched
         `noma_groups` `VecEnviron.step` takes (views of the grouper's state, valid until the next call).
-        `p_off01` [E,N] is the offload power in [0,1] the policy chose (TRAIN:1391-1396).  `prev_global` defaults to the global reward the env's last
+        `p_off01` [E,N] is the offload power in [0,1] the policy chose (TRAIN:1391-1396); alternatively
+        `power_raw` [E,N,2], the SAC power head itself in [-1,1], mapped in-kernel exactly as `marshal_actions`
+        maps it (`risvec_noma_group_raw`).  `prev_global` defaults to the global reward the env's last
         `step` left in `metrics[:,0]` (none before the first step of the episode).  `gdb12` / `gdb15`
         inject a host's float64 dB gains (parity interface); `u_unstick` injects the TRAIN:1539 draw."""
         self._ensure_device()
@@ -255,13 +257,21 @@ class NomaGrouper:
                                               self._stream()))
             tau_back = t["tau"]
         p01 = None
-        if p_off01 is not None:
+        fn = N.load().risvec_noma_group
+        if power_raw is not None:
+            if p_off01 is not None:
+                raise ValueError("give p_off01 or power_raw, not both")
+            p01 = power_raw.to(self.device, torch.float32).contiguous()
+            if tuple(p01.shape) != (self.n_envs, self.n_veh, 2):
+                raise ValueError("power_raw must have shape [n_envs, n_veh, 2]")
+            fn = N.load().risvec_noma_group_raw
+        elif p_off01 is not None:
             p01 = p_off01.to(self.device, torch.float32).contiguous()
             if tuple(p01.shape) != (self.n_envs, self.n_veh):
                 raise ValueError("p_off01 must have shape [n_envs, n_veh]")
         uu = None if u_unstick is None else u_unstick.to(self.device, torch.float32).contiguous()
         self._calls += 1
-        N.check(N.load().risvec_noma_group(
+        N.check(fn(
             C.byref(self._cstate), C.byref(self._params()), _ptr(g), _ptr(self._f64(gdb12)), _ptr(p01),
             1 if (cfg.mask_enable and self._mask_fresh) else 0, int(K_back), _ptr(tau_back),
             _ptr(prev_global), int(stride), int(i_step), _ptr(uu), int(getattr(self.env, "seed", 0)),
@@ -270,7 +280,7 @@ class NomaGrouper:
         self._have_reward = True        # the caller steps the env next; its metrics[:,0] feeds the next call
         return t["partner"], t["n_groups"]
 
-    def bind_group(self, p_off01: Optional[torch.Tensor]):
+    def bind_group(self, p_off01: Optional[torch.Tensor] = None, power_raw: Optional[torch.Tensor] = None):
         """`group()` with everything that does not change from step to step validated and
         marshalled once: returns `launch(i_step)`, one pre-built C-ABI call per step (the frozen
         steps of an episode are launch-bound, so host time matters).  Inputs are read in place:
@@ -283,13 +293,20 @@ class NomaGrouper:
         if not cfg.mask_enable:
             raise ValueError("bind_group needs mask_enable (the cached tau / K of the last refresh_mask)")
         p01 = None
-        if p_off01 is not None:
+        lib, cs, prm = N.load(), C.byref(self._cstate), self._params()
+        fn, check = lib.risvec_noma_group, N.check
+        if power_raw is not None:                     # the SAC power head itself, mapped in-kernel (no marshalling launch)
+            if p_off01 is not None:
+                raise ValueError("give p_off01 or power_raw, not both")
+            if (power_raw.dtype != torch.float32 or power_raw.device != self.device or not power_raw.is_contiguous()
+                    or tuple(power_raw.shape) != (self.n_envs, self.n_veh, 2)):
+                raise ValueError("power_raw must be a contiguous float32 [n_envs, n_veh, 2] tensor on %s" % self.device)
+            p01, fn = power_raw, lib.risvec_noma_group_raw
+        elif p_off01 is not None:
             if (p_off01.dtype != torch.float32 or p_off01.device != self.device or not p_off01.is_contiguous()
                     or tuple(p_off01.shape) != (self.n_envs, self.n_veh)):
                 raise ValueError("p_off01 must be a contiguous float32 [n_envs, n_veh] tensor on %s" % self.device)
             p01 = p_off01
-        lib, cs, prm = N.load(), C.byref(self._cstate), self._params()
-        fn, check = lib.risvec_noma_group, N.check
         g, metrics = self.env._t["gain"], self.env._t["metrics"]
         gp, pp, tp, mp, ip = g.data_ptr(), _ptr(p01), t["tau"].data_ptr(), metrics.data_ptr(), t["info"].data_ptr()
         stride, seed, stream = int(metrics.stride(0)), int(getattr(self.env, "seed", 0)), self._stream()

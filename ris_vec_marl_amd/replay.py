@@ -61,17 +61,27 @@ class VecReplayBuffer:
         return t
 
     # ------------------------------------------------------------------ stores
-    def store_batch(self, state: torch.Tensor, action: torch.Tensor, reward_g: torch.Tensor, reward_l: torch.Tensor,
-                    state_: torch.Tensor, done=False, mask: Optional[torch.Tensor] = None) -> None:
+    def store_batch(self, state: torch.Tensor, action: Optional[torch.Tensor], reward_g: torch.Tensor, reward_l: torch.Tensor,
+                    state_: torch.Tensor, done=False, mask: Optional[torch.Tensor] = None,
+                    policy_out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> None:
         """n consecutive store_transition calls (BUF:16-25), env 0 first.  state / state_ [n, ...]
         (any trailing shape with input_shape*n_agents elements, e.g. the env's obs [E,V,5]); action
         [n, n_actions*n_agents]; reward_g [n] or a strided [n, k] tensor whose column 0 is used
         (the env's metrics); reward_l [n, n_agents]; done: bool or [n] bool/uint8; mask [n, A, A]
-        uint8/bool (the NOMA mask) or None = all ones (TRAIN:1786-1787)."""
+        uint8/bool (the NOMA mask) or None = all ones (TRAIN:1786-1787).
+        `action=None, policy_out=(power_raw [n,A,2], probs [n,A,A])`: the action row is built in the store kernel
+        from the policy outputs (what `marshal_actions` would have written, TRAIN:1386-1390, 1776-1784)."""
         n = int(state.shape[0])
         S, A, L = self.input_shape * self.n_agents, self.n_actions * self.n_agents, self.n_agents
         st, st2 = self._f32(state, (n, S), "state"), self._f32(state_, (n, S), "state_")
-        ac, rl = self._f32(action, (n, A), "action"), self._f32(reward_l, (n, L), "reward_l")
+        rl = self._f32(reward_l, (n, L), "reward_l")
+        ac = pw = pr = None
+        if action is not None:
+            ac = self._f32(action, (n, A), "action")
+        elif policy_out is None:
+            raise ValueError("store_batch: give action or policy_out=(power_raw, probs)")
+        else:
+            pw, pr = self._f32(policy_out[0], (n, L, 2), "power_raw"), self._f32(policy_out[1], (n, L, L), "probs")
         rg = reward_g if isinstance(reward_g, torch.Tensor) else torch.as_tensor(reward_g)
         if rg.dtype != torch.float32 or rg.device != self.device:
             rg = rg.to(self.device, torch.float32)
@@ -92,12 +102,18 @@ class VecReplayBuffer:
             mk = mask.to(self.device)
             mk = (mk != 0).to(torch.uint8).reshape(n, L * L).contiguous() if mk.dtype != torch.uint8 \
                 else mk.reshape(n, L * L).contiguous()
-        N.check(N.load().risvec_replay_store(C.byref(self._c), self.mem_cntr, n, _ptr(st), _ptr(ac), _ptr(rg), int(stride),
-                                             _ptr(rl), _ptr(st2), _ptr(dn), done_all, _ptr(mk), None, self._stream()))
+        if ac is not None:
+            N.check(N.load().risvec_replay_store(C.byref(self._c), self.mem_cntr, n, _ptr(st), _ptr(ac), _ptr(rg), int(stride),
+                                                 _ptr(rl), _ptr(st2), _ptr(dn), done_all, _ptr(mk), None, self._stream()))
+        else:
+            N.check(N.load().risvec_replay_store_policy(C.byref(self._c), self.mem_cntr, n, _ptr(st), _ptr(pw), _ptr(pr),
+                                                        _ptr(rg), int(stride), _ptr(rl), _ptr(st2), _ptr(dn), done_all,
+                                                        _ptr(mk), None, self._stream()))
         self.mem_cntr += n
 
-    def bind_store(self, state: Optional[torch.Tensor], action: torch.Tensor, reward_g: torch.Tensor,
-                   reward_l: torch.Tensor, state_: torch.Tensor, mask: Optional[torch.Tensor] = None):
+    def bind_store(self, state: Optional[torch.Tensor], action: Optional[torch.Tensor], reward_g: torch.Tensor,
+                   reward_l: torch.Tensor, state_: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                   policy_out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         """`store_batch` with the arguments validated and marshalled once: returns `launch(done=False,
         use_mask=True)`, one pre-built C-ABI call that appends the CURRENT contents of the given
         tensors (they are read in place every call: the env's obs / reward / metrics, the marshalled
@@ -106,7 +122,9 @@ class VecReplayBuffer:
         `state=None`: the buffer carries the previous step's `state_` forward itself (the store kernel
         drops a copy of `state_` into a ping-pong buffer while it has it in registers), i.e. the
         driver's `marl_state_old_all = marl_state_new_all` (TRAIN:1277, 1774) without a copy kernel;
-        the first call then stores the CURRENT `state_` as `state`."""
+        the first call then stores the CURRENT `state_` as `state`.
+        `action=None, policy_out=(power_raw, probs)`: the action row is built in the store kernel from the policy
+        outputs, read in place (no marshalling launch; see `store_batch`)."""
         n = int(state_.shape[0])
         carry = None
         if state is None:
@@ -116,16 +134,28 @@ class VecReplayBuffer:
 
         def ok(t, numel, dt=torch.float32):
             return t.dtype == dt and t.device == self.device and t.is_contiguous() and t.numel() == numel
-        if not (ok(state, n * S) and ok(state_, n * S) and ok(action, n * A) and ok(reward_l, n * L)):
-            raise ValueError("bind_store: state/action/reward_l/state_ must be contiguous float32 tensors of n rows on %s"
+        if action is None:
+            if policy_out is None or not (ok(policy_out[0], n * L * 2) and ok(policy_out[1], n * L * L)):
+                raise ValueError("bind_store: without action, policy_out = (power_raw [n,A,2], probs [n,A,A]) contiguous "
+                                 "float32 on %s is needed" % self.device)
+            if self.n_actions != L + 2:
+                raise ValueError("bind_store: the policy-output form needs n_actions = n_agents + 2")
+        elif not ok(action, n * A):
+            raise ValueError("bind_store: action must be a contiguous float32 [n, %d] tensor on %s" % (A, self.device))
+        if not (ok(state, n * S) and ok(state_, n * S) and ok(reward_l, n * L)):
+            raise ValueError("bind_store: state/reward_l/state_ must be contiguous float32 tensors of n rows on %s"
                              % self.device)
         if reward_g.dtype != torch.float32 or reward_g.device != self.device or reward_g.shape[0] != n:
             raise ValueError("bind_store: reward_g must be a float32 tensor with n rows on %s" % self.device)
         stride = int(reward_g.stride(0)) if reward_g.dim() == 2 else 1
         if mask is not None and not ok(mask, n * L * L, torch.uint8):
             raise ValueError("bind_store: mask must be a contiguous uint8 [n, A, A] tensor")
-        fn, check, rb = N.load().risvec_replay_store, N.check, C.byref(self._c)
-        ptrs = (state.data_ptr(), action.data_ptr(), reward_g.data_ptr(), stride, reward_l.data_ptr(), state_.data_ptr())
+        lib, check, rb = N.load(), N.check, C.byref(self._c)
+        if action is not None:
+            fn_a, a_args = lib.risvec_replay_store, (action.data_ptr(),)
+        else:
+            fn_a, a_args = lib.risvec_replay_store_policy, (policy_out[0].data_ptr(), policy_out[1].data_ptr())
+        ptrs = (state.data_ptr(), None, reward_g.data_ptr(), stride, reward_l.data_ptr(), state_.data_ptr())
         mp, stream = _ptr(mask), self._stream()
 
         flip = [0]
@@ -136,11 +166,11 @@ class VecReplayBuffer:
             else:
                 src, dst = carry[flip[0]].data_ptr(), carry[flip[0] ^ 1].data_ptr()
                 flip[0] ^= 1
-            check(fn(rb, self.mem_cntr, n, src, ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5], None,
-                     1 if done else 0, mp if use_mask else None, dst, stream))
+            check(fn_a(rb, self.mem_cntr, n, src, *a_args, ptrs[2], ptrs[3], ptrs[4], ptrs[5], None,
+                       1 if done else 0, mp if use_mask else None, dst, stream))
             self.mem_cntr += n
 
-        launch.keepalive = (state, action, reward_g, reward_l, state_, mask, carry)
+        launch.keepalive = (state, action, policy_out, reward_g, reward_l, state_, mask, carry)
         return launch
 
     def store_transition(self, state, action, reward_g, reward_l, state_, done, mask_flat) -> None:

@@ -156,3 +156,67 @@ def test_marshal_vs_oracle_other_shapes(V):
     assert np.array_equal(env_a.cpu().numpy(), a_o.astype(np.float32))
     assert np.array_equal(p01.cpu().numpy(), p_o.astype(np.float32))
     assert np.array_equal(store.cpu().numpy(), s_o)
+
+
+@pytest.mark.parametrize("V,M", [(8, 36), (6, 16), (5, 16)])
+def test_rollout_without_a_marshal_launch_is_identical(V, M):
+    """The three consumers of the policy outputs can take them directly -- the env through
+    RISVEC_STEP_POLICY_ACTION, the grouping through risvec_noma_group_raw, the replay through
+    risvec_replay_store_policy -- and must then produce exactly what the marshalled path produces
+    (marl_train_bcd.py:1386-1396, 1601-1608, 1776-1784): same groups, same env state, same ring contents."""
+    from ris_vec_marl_amd import NomaGrouper, VecEnviron, VecReplayBuffer, apply_yaml_config, marshal_actions, reference_lanes
+    E, T = 700, 12
+    L = reference_lanes()
+    gen = torch.Generator(device=DEV); gen.manual_seed(3)
+    power = [torch.rand(E, V, 2, device=DEV, generator=gen) * 2.4 - 1.2 for _ in range(T)]
+    probs = [torch.softmax(torch.randn(E, V, V, device=DEV, generator=gen), -1) for _ in range(T)]
+
+    def build():
+        env = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3, n_envs=E,
+                         device=DEV, seed=8)
+        apply_yaml_config(env, None)
+        env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase(); env.update_channel_gains()
+        g = NomaGrouper(env)
+        g.config.qos_enable = True; g.config.qos_R_min_bpsHz = 0.15; g.config.min_pair_target = max(1, V // 3)
+        return env, g, VecReplayBuffer(5 * E, 5, V + 2, V, device=DEV)
+
+    # (a) the marshalled path
+    env, g, buf = build()
+    g.begin_episode(0); mask = g.refresh_mask()
+    state_old = env.observe().clone()
+    for t in range(T):
+        a_env, p01, a_store = marshal_actions(power[t], probs[t], float(env.cpu_share_floor))
+        partner, ng = g.group(p01, t)
+        env.step(a_env, partner, ng, None, fused=True)
+        buf.store_batch(state_old, a_store, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"], t == T - 1, mask)
+        state_old.copy_(env.tensors["obs"])
+    # (b) no marshalling launch: bound launchers reading the policy outputs in place
+    env2, g2, buf2 = build()
+    g2.begin_episode(0); mask2 = g2.refresh_mask()
+    pw, pr = torch.empty(E, V, 2, device=DEV), torch.empty(E, V, V, device=DEV)
+    pw.copy_(power[0])
+    partner2, ng2 = g2.group(None, 0, power_raw=pw)             # unbound form once: gives the state views to bind
+    step = env2.bind_step(pw, partner2, ng2, None, fused=True, policy_action=True)
+    group = g2.bind_group(power_raw=pw)
+    store = buf2.bind_store(None, None, env2.tensors["metrics"], env2.tensors["reward"], env2.tensors["obs"], mask2,
+                            policy_out=(pw, pr))
+    for t in range(T):
+        pw.copy_(power[t]); pr.copy_(probs[t])
+        if t > 0:
+            group(t)
+        step()
+        store(done=t == T - 1, use_mask=True)
+    assert torch.equal(g._t["partner"], g2._t["partner"]) and torch.equal(g._t["n_groups"], g2._t["n_groups"])
+    for k in ("data_buf", "reward", "obs", "metrics", "mec_q", "gain"):
+        assert torch.equal(env.tensors[k], env2.tensors[k]), k
+    assert buf.mem_cntr == buf2.mem_cntr == T * E
+    for k in buf._ARRAYS:
+        assert torch.equal(getattr(buf, k), getattr(buf2, k)), k
+    # and the unbound store_batch(policy_out=...) form
+    buf3 = VecReplayBuffer(2 * E, 5, V + 2, V, device=DEV)
+    buf3.store_batch(state_old, None, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"], False, mask,
+                     policy_out=(power[-1], probs[-1]))
+    _, _, a_store = marshal_actions(power[-1], probs[-1], float(env.cpu_share_floor))
+    assert torch.equal(buf3.action_memory[:E], a_store)
+    with pytest.raises(ValueError):
+        buf3.store_batch(state_old, None, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"])
