@@ -11,8 +11,12 @@ throughput use `VecEnviron` directly.
 Differences a maintainer must know (also in INTEGRATION.md):
   * random draws come from a counter-based Philox stream seeded by `seed=`, not from
     the global `numpy.random` state (`set_seed`, marl_train_bcd.py:32-42, has no effect);
-  * returned arrays are host copies, not live aliases of internal state;
-  * a vehicle may appear in at most one 1- or 2-element NOMA group per step.
+  * returned arrays are host copies, not live aliases of internal state: read right after the call (as the
+    driver does, marl_train_bcd.py:1611-1662) they hold the reference's values; the reference's own tuple
+    keeps changing under the next step (tests/golden/facade_alias_8.npz records how);
+  * `noma_groups` may list a vehicle several times, hold pairs [u, u], groups of other sizes and empty groups:
+    the reference's semantics are reproduced (the last 1- or 2-element group listing a vehicle decides its rate,
+    a partner paired with it earlier keeps the pair rate, every group counts in G; tests/golden/facade_groups_8.npz).
 """
 from __future__ import annotations
 
@@ -36,24 +40,24 @@ def encode_noma_groups(groups_per_env: Sequence[Sequence[Sequence[int]]], n_veh:
     partner[v] = j if v is listed first in the pair [v, j]; j + 65536 if listed second;
     -1 if v is alone in a 1-element group; -2 if v is in no group or in a group of any
     other size (rate 0, Environment.py:336, 344, 351).  n_groups = len(noma_groups),
-    including groups of other sizes, as in Environment.py:341."""
+    including groups of other sizes, as in Environment.py:341.
+
+    The reference walks the list in order and every group OVERWRITES the rates of its members
+    (Environment.py:344-369), so a vehicle listed more than once ends up with the rate of the LAST 1- or
+    2-element group that lists it, while a vehicle that was paired with it earlier keeps the rate it got in
+    that pair.  The encoding is per vehicle (its own partner entry is all a lane reads), so "last writer wins"
+    per entry reproduces exactly that; a pair [u, u] degenerates to the OMA rate, as it does in the reference."""
     E = len(groups_per_env)
     partner = np.full((E, n_veh), N.PARTNER_NONE, dtype=np.int32)
     n_groups = np.zeros(E, dtype=np.int32)
     for e, groups in enumerate(groups_per_env):
         n_groups[e] = len(groups)
-        seen = set()
         for g in groups:
             if len(g) not in (1, 2):
                 continue
             for u in g:
-                u = int(u)
-                if not 0 <= u < n_veh:
-                    raise ValueError("noma_groups: vehicle index %d outside [0, %d)" % (u, n_veh))
-                if u in seen:
-                    raise ValueError("noma_groups: vehicle %d appears in more than one scheduled group "
-                                     "(not representable in the batched encoding)" % u)
-                seen.add(u)
+                if not 0 <= int(u) < n_veh:
+                    raise ValueError("noma_groups: vehicle index %d outside [0, %d)" % (int(u), n_veh))
             if len(g) == 1:
                 partner[e, int(g[0])] = N.PARTNER_SINGLE
             else:

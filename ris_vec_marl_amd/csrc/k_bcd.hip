@@ -161,6 +161,64 @@ k_colsum(Dims d, const float* __restrict__ h_r, const float* __restrict__ b, dou
     }
 }
 
+// k_colsum_slab (M a multiple of 16): the same sums with BOTH sides of the transpose coalesced.  A workgroup owns
+// one slab of 64 envs x 16 elements: eight lanes read one 128-byte line of one vehicle row (two elements per lane,
+// every row of the env in flight at once), the float64 column sums go through a [16][64] LDS tile, and the
+// workgroup writes sixteen 1-KiB runs of the lane-major cache.  k_colsum<2> above reads just as well but scatters
+// its 16-byte stores 2 KiB apart (343 us at 32 768 x 16 x 256 = 44 % of the HBM peak, profiles/r01p_*).
+constexpr int kSlabM = 16;                                  // elements per tile
+constexpr int kSlabRow = kWave + 1;                         // LDS row stride (double2 units): staggers the banks
+
+constexpr int kSlabThreads = 8 * kWave;                    // 8 lanes per (env, 128-byte line), 64 envs
+
+template <int VU>                                           // vehicle rows a lane keeps in flight (VU >= V)
+__global__ void __launch_bounds__(kSlabThreads)
+k_colsum_slab(Dims d, const float* __restrict__ h_r, const float* __restrict__ b, double* __restrict__ c_col) {
+    __shared__ double2 s_c[kSlabM * kSlabRow];              // 16 640 B
+    const int M = d.M, V = d.V, NP = M >> 1;
+    const int tiles = M / kSlabM;
+    const int slab = blockIdx.x;                            // a workgroup walks the 16-element tiles of its slab in order:
+                                                            // the rows it touches stay open / cached from tile to tile
+    const int l8 = threadIdx.x & 7, el = threadIdx.x >> 3; // element pair inside the tile, env inside the slab
+    long long e = (long long)slab * kWave + el;
+    e = e < d.E ? e : d.E - 1;                              // tail slab: re-read the last env (never used by a live lane)
+    const float4* __restrict__ he = reinterpret_cast<const float4*>(h_r) + e * V * NP + l8;
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(b) + l8;
+    double2* __restrict__ out = reinterpret_cast<double2*>(c_col) + (long long)slab * M * kWave;
+    struct Rows { float4 h[VU]; };
+    auto fetch = [&](Rows& r, int tile) {
+        const int tc = tile < tiles ? tile : tiles - 1;
+#pragma unroll
+        for (int k = 0; k < VU; ++k) r.h[k] = he[(long long)(k < V ? k : V - 1) * NP + tc * (kSlabM / 2)];
+    };
+    auto do_tile = [&](int tile, const Rows& cur, Rows& nxt) {
+        fetch(nxt, tile + 1);                               // the next tile's rows are in flight during this tile's stores
+        const float4 bb = b4[tile * (kSlabM / 2)];
+        double s0r = 0.0, s0i = 0.0, s1r = 0.0, s1i = 0.0;
+#pragma unroll
+        for (int k = 0; k < VU; ++k) {
+            const bool ok = k < V;
+            s0r += ok ? (double)cur.h[k].x : 0.0; s0i += ok ? (double)cur.h[k].y : 0.0;
+            s1r += ok ? (double)cur.h[k].z : 0.0; s1i += ok ? (double)cur.h[k].w : 0.0;
+        }
+        s_c[(2 * l8) * kSlabRow + el] = make_double2(s0r * bb.x - s0i * bb.y, s0r * bb.y + s0i * bb.x);
+        s_c[(2 * l8 + 1) * kSlabRow + el] = make_double2(s1r * bb.z - s1i * bb.w, s1r * bb.w + s1i * bb.z);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kSlabM * kWave / kSlabThreads; ++i) {
+            const int idx = threadIdx.x + i * kSlabThreads; // m_local * 64 + env: consecutive lanes, consecutive envs
+            out[(long long)tile * kSlabM * kWave + idx] = s_c[(idx >> 6) * kSlabRow + (idx & 63)];
+        }
+        __syncthreads();
+    };
+    Rows ra, rb;
+    fetch(ra, 0);
+    for (int tile = 0; tile < tiles; tile += 2) {
+        do_tile(tile, ra, rb);
+        if (tile + 1 < tiles) do_tile(tile + 1, rb, ra);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // k_bcd_sweep
 // ---------------------------------------------------------------------------
@@ -610,6 +668,15 @@ k_bcd_sweep8_idx(Dims d, const double* __restrict__ c_col, float* __restrict__ t
 // launchers
 // ---------------------------------------------------------------------------
 hipError_t launch_colsum(const RisVecState& s, hipStream_t st) {
+    static const bool no_slab = std::getenv("RISVEC_NO_COLSUM_SLAB") != nullptr;       // A/B switch for experiments
+    if (s.n_ris % kSlabM == 0 && s.n_veh <= 16 && !no_slab) {
+        const long long blocks = ((long long)s.n_envs + kWave - 1) / kWave;
+        if (blocks < (1LL << 31)) {
+            if (s.n_veh <= 8) hipLaunchKernelGGL(k_colsum_slab<8>, dim3((unsigned)blocks), dim3(kSlabThreads), 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+            else hipLaunchKernelGGL(k_colsum_slab<16>, dim3((unsigned)blocks), dim3(kSlabThreads), 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+            return hipGetLastError();
+        }
+    }
     const bool even = (s.n_ris & 1) == 0;
     const long long n_slot = (long long)s.n_envs * (even ? s.n_ris / 2 : s.n_ris);
     const unsigned grid = (unsigned)((n_slot + kBlock / 2 - 1) / (kBlock / 2));

@@ -387,3 +387,49 @@ def test_multi_step_launch_options_and_errors():
             torch.as_tensor(ngt).cuda().data_ptr(), None, 0, 0)
     assert lib.risvec_step_fused_multi(*args, N.STEP_STEER, None, None) == N.ERR_ARG
     assert lib.risvec_step_fused_multi(*args[:2], 0, *args[3:], 0, None, None) == N.ERR_ARG
+
+
+# ---------------------------------------------------------------------------- facade: reference semantics of odd group lists
+def test_facade_takes_the_group_lists_the_reference_takes():
+    """`Environ.step(action, noma_groups)` with a vehicle in several groups, pairs [u, u], groups of 3+ and empty
+    groups against the reference's own outputs (tests/golden/facade_groups_8.npz, Environment.py:339-369), and the
+    returned arrays are copies (the reference's are live aliases: tests/golden/facade_alias_8.npz)."""
+    from ris_vec_marl_amd import Environ, reference_lanes
+    from tests.test_hip_parity import load, set_params
+    g = load("facade_groups_8.npz")
+    n, V = g["gain"].shape
+    L = reference_lanes()
+    env = Environ(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, 16, 3, device="cuda:0")
+    env.make_new_game()
+    p = orc.OracleParams.yaml_effective()
+    set_params(env, p)
+    worst = 0.0
+    n_checked = 0
+    for i in range(0, n, 2):
+        groups = [[int(u) for u in g["groups"][i, k, :m]] for k, m in enumerate(g["group_len"][i]) if m >= 0]
+        env.DataBuf = g["data_buf0"][i]; env.mec_queue_cycles = g["mec_q0"][i]; env.channel_gains = g["gain"][i]
+        r = env.step(g["action"][i], groups, arrivals=g["arrivals"][i])
+        # the float32 image of the inputs through the oracle: masks for threshold proximity
+        partner, ng = orc.encode_groups(groups, V)
+        o = orc.step(g["data_buf0"][i][None].astype(np.float32).astype(np.float64), np.array([np.float32(g["mec_q0"][i])], dtype=np.float64),
+                     g["gain"][i][None].astype(np.float32).astype(np.float64), g["action"][i][None], partner[None], np.array([ng]),
+                     g["arrivals"][i][None], p)
+        near_qos, near_other = step_mask(o, partner[None], g["gain"][i][None], np.array([g["mec_q0"][i]]))
+        ok = ~near_other[0]
+        rate = np.asarray(env.vehicle_rate)
+        assert (np.abs(rate - g["vehicle_rate"][i]) <= RT * g["vehicle_rate"][i] + 1e-7)[ok].all(), i
+        okr = ok & ~near_qos[0]
+        d_scale = g["data_buf0"][i] * 1000 * p.cycles_per_bit / (p.cpu_share_floor * p.f_local_max)
+        err = np.abs(np.asarray(r[0]) - g["reward"][i])
+        # inputs were rounded to float32 on upload: |oracle(float32 inputs) - reference| is that rounding, evaluated exactly
+        tol = RT * np.abs(g["reward"][i]) + 4e-7 * p.w_d * d_scale + 1e-9 + np.abs(o["reward"][0] - g["reward"][i])
+        assert (err <= tol)[okr].all(), i
+        if okr.any():
+            worst = max(worst, float((err / np.abs(g["reward"][i]))[okr].max()))
+        n_checked += int(okr.sum())
+    assert n_checked > 0.9 * (n // 2) * V
+    print("facade odd group lists: max reward rel err vs the reference %.2e" % worst)
+    # copies, not aliases
+    a = np.asarray(r[3]).copy()
+    env.step(g["action"][0], [[0], [1]], arrivals=g["arrivals"][0])
+    assert np.array_equal(np.asarray(r[3]), a)

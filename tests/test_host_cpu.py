@@ -121,8 +121,10 @@ def test_encode_noma_groups():
     assert ng[0] == 5 and n == 4
     assert np.array_equal(partner[0], want)
     assert partner[0, 0] == 3 and partner[0, 3] == 0 + (1 << 16) and partner[0, 1] == -1 and partner[0, 6] == -2
-    with pytest.raises(ValueError):
-        rv.encode_noma_groups([[[0, 1], [1]]], 8)
+    # a vehicle listed twice: the last group that lists it decides (Environment.py:344-369; pinned by
+    # tests/golden/facade_groups_8.npz), its earlier partner keeps the pair entry
+    p1, n1 = rv.encode_noma_groups([[[0, 1], [1]]], 8)
+    assert p1[0, 0] == 1 and p1[0, 1] == -1 and n1[0] == 2
     with pytest.raises(ValueError):
         rv.encode_noma_groups([[[0, 9]]], 8)
     p2, n2 = rv.encode_noma_groups([[], [[2]]], 4)
