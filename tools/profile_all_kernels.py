@@ -26,6 +26,7 @@ partner = torch.full((E, V), -1, dtype=torch.int32).cuda()
 ng = torch.full((E,), V, dtype=torch.int32).cuda()
 phase = torch.from_numpy(rng.uniform(0, 6.28, (E, M)).astype(np.float32)).cuda()
 pw = action[:, 0, :].contiguous()
+actions_T = torch.from_numpy(rng.uniform(0, 1, (16, E, 2, V)).astype(np.float32)).cuda()
 grouper = NomaGrouper(env) if V <= 16 else None
 replay = VecReplayBuffer(3 * E, 5, V + 2, V, device="cuda:0")
 power_raw = torch.from_numpy(rng.uniform(-1, 1, (E, V, 2)).astype(np.float32)).cuda()
@@ -39,12 +40,15 @@ for _ in range(reps):
     env.compute_parms()                # k_geometry + k_colsum
     env.Random_phase()
     env.get_next_phase(phase)
-    env.optimize_phase_shift()         # k_bcd_sweep (column sums cached)
+    env.optimize_phase_shift()         # k_bcd_sweep: the generic sweep (theta set by hand: indices unknown), column sums cached
+    env.optimize_phase_shift()         # k_bcd_sweep8_idx: the indexed sweep (indices left by the previous one, cached sum)
     env.update_channel_gains()         # k_gain
     env.data_rate(pw, partner, ng)
     env.step(action, partner, ng, None, fused=False, power_w=False)
     env.step(action, partner, ng, None, fused=True, power_w=False)
     env.step(action, partner, ng, None, fused=True, power_w=False, steer=True)      # k_step_steer
+    if (V, M) in ((8, 64), (8, 36), (8, 40), (4, 16)):
+        env.step_many(actions_T, partner, ng, None)                   # k_step_fused_lat<.., MULTI>: T = 16 steps in one launch
     env.sarl_step(action, phase)
     env.channel_model = "3gpp_umi"
     env.update_channel_gains()
@@ -70,7 +74,9 @@ torch.cuda.synchronize()
 B = dict(
     k_reset=E * V * (16 + 4 + 4 + 4), k_mobility=E * V * (16 + 4 + 4 + 16 + 4), k_geometry=E * V * (16 + 12 + 8 * M),
     k_colsum=E * (8 * V * M + 16 * M), k_random_phase=E * 8 * M, k_set_phase=E * 12 * M,
-    k_bcd_sweep=E * (2 * 16 * M + 2 * 8 * M + 8 * M), k_gain=E * (8 * V * M + 8 * M + 8 * V),
+    k_bcd_sweep=E * (2 * 16 * M + 2 * 8 * M + 8 * M), k_bcd_sweep8_idx=E * (16 * M + 2 * M + 8 * M + 32),
+    k_colsum_slab=E * (8 * V * M + 16 * M),
+    k_step_fused_lat=E * (8 * V * M + 8 * M + 16 * (8 * V + 24 * V + 64) + 40 * V + 8), k_gain=E * (8 * V * M + 8 * M + 8 * V),
     k_data_rate=E * 16 * V + 4 * E, k_step=E * (60 * V + 68), k_step_fused=E * (8 * V * M + 8 * M + 64 * V + 68),
     k_step_steer=E * (16 * V + 8 * M + 64 * V + 68),
     k_sarl_step=E * (8 * V * M + 8 * M + 48 * V + 4), k_gain_3gpp=E * V * 20,
