@@ -122,7 +122,8 @@ class RisVecReplay(C.Structure):
 NOMA_MAX_VEH = 16
 NOMA_HAS_LAST, NOMA_UNSTICK_USED, NOMA_HAS_GROUPS = 1, 2, 4
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librisvec.so")
+LIB_PATH = os.environ.get("RISVEC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librisvec.so")
+# (RISVEC_LIB: an alternative build of the same library, for A/B experiments)
 
 _PROTOS = {
     "risvec_abi_version": (C.c_uint32, []),

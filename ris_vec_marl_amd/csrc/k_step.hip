@@ -48,7 +48,7 @@ k_step(Dims d, RisVecParams P, StepArgs A) {
     const bool active = e < d.E && v < d.V;
     const StepIn in = load_step_in(d, A, e, v, active);
     const float g = active ? A.gain[(long long)e * d.V + v] : 0.f;
-    step_core<VP>(d, P, A, e, v, active, g, in);
+    step_core<VP, false, true>(d, P, A, e, v, active, g, in);
 }
 
 // compute_data_rate as its own entry point (ENV:331-372)

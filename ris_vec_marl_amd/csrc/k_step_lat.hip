@@ -132,7 +132,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
         A.gain[idx] = g;
     }
     if constexpr (!MULTI) {
-        step_core<VP>(d, P, A, e_mine, v_mine, active, g, in);
+        step_core<VP, false, true>(d, P, A, e_mine, v_mine, active, g, in);
     } else {
         const long long ev = (long long)d.E * V;
         const bool pol = (A.flags & RISVEC_STEP_POLICY_ACTION) != 0;
@@ -159,7 +159,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
             tj.obs = TJ.obs ? TJ.obs + (long long)t * ev * 5 : nullptr;
             tj.metrics = TJ.metrics ? TJ.metrics + (long long)t * d.E * RISVEC_METRICS : nullptr;
             tj.store_state = t == n_steps - 1;
-            const StepCarry c = step_core<VP, true>(d, P, At, e_mine, v_mine, active, g, in, &tj);
+            const StepCarry c = step_core<VP, true, true>(d, P, At, e_mine, v_mine, active, g, in, &tj);
             in.B = c.B;
             in.Q0 = c.Q;
             in.a0 = a0n;

@@ -54,13 +54,19 @@ __device__ __forceinline__ int randint_u32(uint32_t x, int low, int high) {
 
 // Poisson(lambda) by inversion against the host-built float32 CDF table: the count
 // of table entries <= u.  The loop is wave-uniform (exits when no lane advances).
+// The first 8 entries are counted branch-free (a compare + add each: at the shipped rates 1 and 3 a draw above
+// 7 has probability 1e-6 / 4e-3); the loop over the rest of the table runs only when some lane needs it.
 __device__ __forceinline__ int poisson_from_u(float u, const float* __restrict__ cdf) {
     int n = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) n += u >= cdf[k] ? 1 : 0;
+    if (__any(u >= cdf[7])) {
 #pragma unroll 1
-    for (int k = 0; k < RISVEC_POISSON_TABLE; ++k) {
-        const bool ge = u >= cdf[k];
-        if (!__any(ge)) break;
-        n += ge ? 1 : 0;
+        for (int k = 8; k < RISVEC_POISSON_TABLE; ++k) {
+            const bool ge = u >= cdf[k];
+            if (!__any(ge)) break;
+            n += ge ? 1 : 0;
+        }
     }
     return n;
 }

@@ -38,27 +38,6 @@ struct Unit {
     float4 t[NIT];
 };
 
-// transposing butterfly over a G-lane group: K values in, after log2(K) halving steps one
-// value per lane, then plain all-reduce steps down to distance 1.
-template <int K, int O>
-__device__ __forceinline__ void treduce(float (&val)[8], int gl) {
-    if constexpr (O >= 1) {
-        if constexpr (K > 1) {
-            const bool hi = (gl & O) != 0;
-#pragma unroll
-            for (int j = 0; j < K / 2; ++j) {
-                const float send = hi ? val[j] : val[j + K / 2];
-                const float keep = hi ? val[j + K / 2] : val[j];
-                val[j] = keep + xchg<O>(send);
-            }
-            treduce<K / 2, O / 2>(val, gl);
-        } else {
-            val[0] += xchg<O>(val[0]);
-            treduce<1, O / 2>(val, gl);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // What runs on the reduced cascade sums: the pipeline is the same for the MARL step, the SARL
 // step and the gain-only kernel; a Core supplies its parameter / argument types, the per-lane

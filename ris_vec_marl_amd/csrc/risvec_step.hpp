@@ -66,27 +66,52 @@ __device__ __forceinline__ double xchg(double x) {
     return __hiloint2double(__builtin_bit_cast(int, hi), __builtin_bit_cast(int, lo));
 }
 
+// all-reduce (sum) over aligned groups of W lanes: a butterfly from the LARGEST distance down, i.e. the same
+// pairings in the same order as the transposing reduction `treduce` below -- so a value summed by either comes out
+// bit-identical (every lane evaluates the same tree: level k groups the lanes into the same partition whichever lane
+// one starts from), which lets the latency-shaped kernels use `treduce` for the per-env metrics and still match the
+// software pipeline to the last bit.
 template <int W>
 __device__ __forceinline__ double gsum(double x) {
-    if constexpr (W >= 2) x += xchg<1>(x);
-    if constexpr (W >= 4) x += xchg<2>(x);
-    if constexpr (W >= 8) x += xchg<4>(x);
-    if constexpr (W >= 16) x += xchg<8>(x);
-    if constexpr (W >= 32) x += xchg<16>(x);
     if constexpr (W >= 64) x += xchg<32>(x);
+    if constexpr (W >= 32) x += xchg<16>(x);
+    if constexpr (W >= 16) x += xchg<8>(x);
+    if constexpr (W >= 8) x += xchg<4>(x);
+    if constexpr (W >= 4) x += xchg<2>(x);
+    if constexpr (W >= 2) x += xchg<1>(x);
     return x;
 }
 
-// all-reduce (sum) over aligned groups of W lanes, ascending butterfly
 template <int W>
 __device__ __forceinline__ float gsum(float x) {
-    if constexpr (W >= 2) x += xchg<1>(x);
-    if constexpr (W >= 4) x += xchg<2>(x);
-    if constexpr (W >= 8) x += xchg<4>(x);
-    if constexpr (W >= 16) x += xchg<8>(x);
-    if constexpr (W >= 32) x += xchg<16>(x);
     if constexpr (W >= 64) x += xchg<32>(x);
+    if constexpr (W >= 32) x += xchg<16>(x);
+    if constexpr (W >= 16) x += xchg<8>(x);
+    if constexpr (W >= 8) x += xchg<4>(x);
+    if constexpr (W >= 4) x += xchg<2>(x);
+    if constexpr (W >= 2) x += xchg<1>(x);
     return x;
+}
+
+// transposing butterfly over a G-lane group: K values in, after log2(K) halving steps one
+// value per lane, then plain all-reduce steps down to distance 1.
+template <int K, int O, int N>
+__device__ __forceinline__ void treduce(float (&val)[N], int gl) {
+    if constexpr (O >= 1) {
+        if constexpr (K > 1) {
+            const bool hi = (gl & O) != 0;
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) {
+                const float send = hi ? val[j] : val[j + K / 2];
+                const float keep = hi ? val[j + K / 2] : val[j];
+                val[j] = keep + xchg<O>(send);
+            }
+            treduce<K / 2, O / 2, N>(val, gl);
+        } else {
+            val[0] += xchg<O>(val[0]);
+            treduce<1, O / 2, N>(val, gl);
+        }
+    }
 }
 
 // a / b as a * rcp(b): v_rcp_f32 is 1 ulp, the product adds 0.5 -> <= 1.5 ulp (1e-7), two
@@ -229,7 +254,10 @@ struct StepCarry {
 // `active` masks lanes beyond V or E.  TRAJ = false is the single-step form (every output
 // goes to the env's tensors); TRAJ = true additionally honours `tj`.
 // ---------------------------------------------------------------------------
-template <int VP, bool TRAJ = false>
+// TM = true: the per-env metrics through one transposing reduction (fewer instructions: the choice of the
+// latency-shaped kernels); TM = false: one butterfly per metric, lane 0 stores four float4 (the software pipeline:
+// its 16-byte stores are a little kinder to a kernel that is busy streaming h_r).  Same values bit for bit.
+template <int VP, bool TRAJ = false, bool TM = false>
 __device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams& P, const StepArgs& A,
                                                int e, int v, bool active, float gain, const StepIn& in,
                                                const StepTraj* tj = nullptr) {
@@ -332,7 +360,6 @@ __device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams
 
     // (13) ENV:721-729
     const float over_power = fmaxf(0.f, (pw0 + pw1) - P.p_max);
-    const float rew_sum = gsum<VP>(active ? rew : 0.f);
     const float inv_v = __builtin_amdgcn_rcpf((float)V);
 
     bool store_state = true;
@@ -366,6 +393,42 @@ __device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams
         }
     }
 
+    if constexpr (TM && (VP == 4 || VP == 8 || VP == 16)) {
+        if ((A.flags & RISVEC_STEP_METRICS) && V == VP) {
+            // The 14 per-env scalars as ONE transposing reduction per VP values instead of one 3-/4-step butterfly
+            // each (36 exchanges -> 14 at VP = 8): slot s is contributed by every lane of the env (the two
+            // per-env values Q and the MEC utilisation by lane 0 only), lands on lane s % VP, which scales and
+            // stores it -- metrics[e][s] leaves as one float per lane, 64 contiguous bytes per env.
+            const float z = 0.f;
+            const bool lead = active && v == 0;
+            float c[16];
+            c[0] = active ? rew : z;  c[1] = active ? off : z;  c[2] = active ? data_p : z;  c[3] = lead ? Q : z;
+            c[4] = active ? B : z;    c[5] = active ? d_loc : z; c[6] = active ? d_q : z;    c[7] = active ? d_c : z;
+            c[8] = active ? t_tx : z; c[9] = lead ? fdiv(svc, edge_cap + 1e-12f) : z;
+            c[10] = active ? fdiv(used, cap + 1e-12f) : z;       c[11] = (active && viol) ? 1.f : z;
+            c[12] = active ? delay : z; c[13] = active ? energy : z; c[14] = z; c[15] = z;
+            bool store_state = true;
+            if constexpr (TRAJ) store_state = tj->store_state;
+#pragma unroll
+            for (int p0 = 0; p0 < 16; p0 += VP) {
+                float part[VP];
+#pragma unroll
+                for (int j = 0; j < VP; ++j) part[j] = c[p0 + j];
+                treduce<VP, VP / 2, VP>(part, v);
+                const int slot = p0 + v;
+                const bool is_sum = slot == 1 || slot == 2 || slot == 3 || slot == 9;
+                const float val = part[0] * (is_sum ? 1.f : inv_v);
+                if (active) {
+                    if (store_state) A.metrics[(long long)e * RISVEC_METRICS + slot] = val;
+                    if constexpr (TRAJ) {
+                        if (tj->metrics) tj->metrics[(long long)e * RISVEC_METRICS + slot] = val;
+                    }
+                }
+            }
+            return StepCarry{Bn, Q};
+        }
+    }
+    const float rew_sum = gsum<VP>(active ? rew : 0.f);
     if (A.flags & RISVEC_STEP_METRICS) {
         const float z = 0.f;
         const float s_off = gsum<VP>(active ? off : z);
