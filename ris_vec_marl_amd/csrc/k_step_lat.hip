@@ -26,7 +26,9 @@
 
 namespace risvec {
 
-template <int V, int M, int EPWT, bool MULTI>
+// STAMP: diagnostic build (tools/lat_stamps.py): TJ.reward is a debug buffer that receives, per wavefront, the
+// s_memrealtime (100 MHz) of: entry, all loads issued, cascade reduced (loads returned), step() done, stores drained.
+template <int V, int M, int EPWT, bool MULTI, bool STAMP = false>
 __global__ void __launch_bounds__(kBlock)
 k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ) {
     using S = PipeShape<V, M>;
@@ -40,6 +42,8 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     const int gl = lane % G, gv = lane / G;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
     const int e0 = wid * EPWT;
+    unsigned long long ts[5] = {0, 0, 0, 0, 0};
+    if constexpr (STAMP) ts[0] = __builtin_amdgcn_s_memrealtime();
     if (e0 >= d.E) return;                                     // whole wave
     const int v_mine = lane % VP, e_mine = e0 + lane / VP;
     const bool active = (lane / VP) < EPWT && e_mine < d.E;
@@ -61,6 +65,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     }
     // Units are loaded in batches of up to 4 (all of them when the wavefront owns <= 4 envs: one memory
     // round trip); the multi-step form may own 64/VP envs, where the gain phase is amortised over the steps.
+    if constexpr (STAMP) ts[1] = __builtin_amdgcn_s_memrealtime();
     constexpr int UB = NU > 4 ? 4 : NU;
     static_assert(NU % UB == 0, "unit batches must tile the wavefront's units");
     float2 w0[NIT], w1[NIT];
@@ -124,6 +129,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
         }
     }
     __builtin_amdgcn_wave_barrier();                           // own LDS writes -> own reads (in order per wave)
+    if constexpr (STAMP) ts[2] = __builtin_amdgcn_s_memrealtime();
     const float2 img = *reinterpret_cast<const float2*>(&s_img[wave][lane * 2]);
     const long long idx = (long long)e_mine * V + v_mine;
     float g = 0.f;
@@ -131,7 +137,17 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
         g = gain_from_img(img, in.pl, A.h_d, idx);
         A.gain[idx] = g;
     }
-    if constexpr (!MULTI) {
+    if constexpr (STAMP) {
+        step_core<VP, false, true>(d, P, A, e_mine, v_mine, active, g, in);
+        asm volatile("" ::: "memory");
+        ts[3] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[4] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(TJ.reward) + (long long)wid * 5;
+            dbg[0] = ts[0]; dbg[1] = ts[1]; dbg[2] = ts[2]; dbg[3] = ts[3]; dbg[4] = ts[4];
+        }
+    } else if constexpr (!MULTI) {
         step_core<VP, false, true>(d, P, A, e_mine, v_mine, active, g, in);
     } else {
         const long long ev = (long long)d.E * V;
@@ -226,6 +242,15 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
     const int epwt = lat_epwt(s.n_envs, epw);
     if (epwt <= 0) return hipErrorNotSupported;
     const RisVecTraj none{nullptr, nullptr, nullptr};
+    if (const char* dbg = std::getenv("RISVEC_LAT_STAMPS_PTR")) {      // diagnostic build, tools/lat_stamps.py
+        if (s.n_veh == 8 && s.n_ris == 36 && epwt == 2) {
+            const RisVecTraj tj{reinterpret_cast<float*>(std::strtoull(dbg, nullptr, 0)), nullptr, nullptr};
+            const long long waves = ((long long)s.n_envs + 1) / 2;
+            hipLaunchKernelGGL((k_step_fused_lat<8, 36, 2, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, st,
+                               dims_of(s), p, a, 1, tj);
+            return hipGetLastError();
+        }
+    }
     return dispatch_lat<false>(s, p, a, 1, none, epwt, st);
 }
 
