@@ -36,6 +36,7 @@ k_episode_clear(int E, int A, double* __restrict__ acc) {
 __global__ void __launch_bounds__(kWave)
 k_episode_accumulate(int E, int V, const float* __restrict__ metrics, const float* __restrict__ reward,
                      const float* __restrict__ power_w, float user_clip, double* __restrict__ acc) {
+    RISVEC_ARGS_IN_ONE_TRIP("s"(E), "s"(V), "s"(metrics), "s"(reward), "s"(power_w), "s"(acc));
     const int e = blockIdx.x * kWave + threadIdx.x;
     if (e >= E) return;
     const size_t S = (size_t)E;

@@ -294,6 +294,11 @@ k_noma_group(NomaArgs A) {
     __shared__ signed char s_arg[S::DP];               // choice taken at each state, for the walk-back
     constexpr bool kRanked = NMAX > S::KPLAIN;         // more users than the plain 2^K table can hold?
     __shared__ uint16_t s_clo[kRanked ? 256 : 1], s_chi[kRanked ? 9 * 128 : 1];   // colex-rank lookup
+    // a frozen step is a handful of loads and stores per env: every argument it touches in ONE scalar round trip
+    RISVEC_ARGS_IN_ONE_TRIP("s"(A.ns.n_envs), "s"(A.ns.n_veh), "s"(A.ns.flags), "s"(A.ns.last_global), "s"(A.ns.best_global),
+                            "s"(A.prev_global), "s"(A.prev_stride), "s"(A.ns.pending), "s"(A.ns.n_groups), "s"(A.u_unstick),
+                            "s"(A.P.freeze_group_in_episode), "s"(A.P.freeze_recalc_every), "s"(A.i_step),
+                            "s"(A.P.freeze_reward_drop_ratio), "s"(A.P.freeze_unstick_prob), "s"(A.info_out));
     const int lane = threadIdx.x;
     const int N = A.ns.n_veh, NN = N * N;
     const RisVecNomaParams& P = A.P;

@@ -45,6 +45,10 @@ template <> __device__ __forceinline__ float4 ones<4>() { return make_float4(1.0
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_replay_store(StoreArgs A) {
+    RISVEC_ARGS_IN_ONE_TRIP("s"(A.n), "s"(A.cursor), "s"(A.rb.mem_size), "s"(A.rb.n_agents), "s"(A.rb.input_shape),
+                            "s"(A.rb.n_actions), "s"(A.state), "s"(A.action), "s"(A.power_raw), "s"(A.probs), "s"(A.reward_l),
+                            "s"(A.state_), "s"(A.mask), "s"(A.carry), "s"(A.rb.state_memory), "s"(A.rb.action_memory),
+                            "s"(A.rb.reward_local_memory), "s"(A.rb.new_state_memory), "s"(A.rb.mask_memory));
     using F = typename Pack<VEC>::F;
     using U = typename Pack<VEC>::U;
     const RisVecReplay& rb = A.rb;
@@ -191,6 +195,7 @@ k_marshal_actions(int E, int V, const float* power_raw, const float* probs, floa
 __global__ void __launch_bounds__(kBlock)
 k_marshal_pairs(int E, int V, const float* power_raw, const float* probs, float floor_eff, float* action_env,
                 float* p_off01, float* action_store) {
+    RISVEC_ARGS_IN_ONE_TRIP("s"(E), "s"(V), "s"(power_raw), "s"(probs), "s"(action_env), "s"(p_off01), "s"(action_store));
     const unsigned gid = blockIdx.x * kBlock + threadIdx.x;    // E*V*(V+2)/2 < 2^31 is checked by the API
     const unsigned H = (unsigned)V / 2 + 1;                    // float2 per row
     if (gid >= (unsigned)E * V * H) return;

@@ -44,7 +44,9 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     const int e0 = wid * EPWT;
     unsigned long long ts[5] = {0, 0, 0, 0, 0};
     if constexpr (STAMP) ts[0] = __builtin_amdgcn_s_memrealtime();
-    if (e0 >= d.E) return;                                     // whole wave
+    // No early exit for the (at most three) surplus wavefronts of the last workgroup: a branch on d.E here costs every
+    // wavefront a scalar-load round trip (cold scalar cache, ~0.35 us) BEFORE the kernel-argument pointers are even
+    // requested.  Surplus wavefronts run with every lane inactive; all their addresses are clamped to the last env.
     const int v_mine = lane % VP, e_mine = e0 + lane / VP;
     const bool active = (lane / VP) < EPWT && e_mine < d.E;
 
@@ -143,7 +145,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
         ts[3] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
+        if (lane == 0 && e0 < d.E) {
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(TJ.reward) + (long long)wid * 5;
             dbg[0] = ts[0]; dbg[1] = ts[1]; dbg[2] = ts[2]; dbg[3] = ts[3]; dbg[4] = ts[4];
         }

@@ -8,6 +8,14 @@
 
 namespace risvec {
 
+// Kernel arguments arrive through scalar loads from a cold scalar cache (every launch starts cold): left alone, the
+// compiler fetches the argument a first branch depends on, waits (~0.35 us), branches, and only then requests the
+// pointers -- two or more dependent round trips in front of a kernel's first memory request.  Naming the arguments a
+// kernel needs first in one `asm volatile("" :: "s"(..))` makes them one batch, one wait.  Matters for every kernel
+// that lives only a few microseconds (k_step_fused_lat at BASELINE configs[1]: 0.74 -> 0.44 us before the first
+// request is out; the C4 shard 8.1 -> 7.2 us per step).
+#define RISVEC_ARGS_IN_ONE_TRIP(...) asm volatile("" ::__VA_ARGS__)
+
 constexpr int kWave = 64;      // CDNA wavefront width (hard-coded on purpose)
 constexpr int kBlock = 256;    // 4 waves per workgroup, one per SIMD
 
