@@ -171,7 +171,7 @@ constexpr int kSlabRow = kWave + 1;                         // LDS row stride (d
 
 constexpr int kSlabThreads = 8 * kWave;                    // 8 lanes per (env, 128-byte line), 64 envs
 
-template <int VU>                                           // vehicle rows a lane keeps in flight (VU >= V)
+template <int VU, bool NT>                                  // VU: vehicle rows a lane keeps in flight (VU >= V); NT: non-temporal loads
 __global__ void __launch_bounds__(kSlabThreads)
 k_colsum_slab(Dims d, const float* __restrict__ h_r, const float* __restrict__ b, double* __restrict__ c_col) {
     __shared__ double2 s_c[kSlabM * kSlabRow];              // 16 640 B
@@ -189,7 +189,16 @@ k_colsum_slab(Dims d, const float* __restrict__ h_r, const float* __restrict__ b
     auto fetch = [&](Rows& r, int tile) {
         const int tc = tile < tiles ? tile : tiles - 1;
 #pragma unroll
-        for (int k = 0; k < VU; ++k) r.h[k] = he[(long long)(k < V ? k : V - 1) * NP + tc * (kSlabM / 2)];
+        for (int k = 0; k < VU; ++k) {
+            const float4* src = he + ((long long)(k < V ? k : V - 1) * NP + tc * (kSlabM / 2));
+            if (NT) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src));
+                r.h[k] = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                r.h[k] = *src;
+            }
+        }
     };
     auto do_tile = [&](int tile, const Rows& cur, Rows& nxt) {
         fetch(nxt, tile + 1);                               // the next tile's rows are in flight during this tile's stores
@@ -672,8 +681,16 @@ hipError_t launch_colsum(const RisVecState& s, hipStream_t st) {
     if (s.n_ris % kSlabM == 0 && s.n_veh <= 16 && !no_slab) {
         const long long blocks = ((long long)s.n_envs + kWave - 1) / kWave;
         if (blocks < (1LL << 31)) {
-            if (s.n_veh <= 8) hipLaunchKernelGGL(k_colsum_slab<8>, dim3((unsigned)blocks), dim3(kSlabThreads), 0, st, dims_of(s), s.h_r, s.b, s.c_col);
-            else hipLaunchKernelGGL(k_colsum_slab<16>, dim3((unsigned)blocks), dim3(kSlabThreads), 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+            // h_r streams larger than the Infinity Cache are read with the non-temporal hint (see launch_pipe)
+            const bool nt = (long long)s.n_envs * s.n_veh * s.n_ris * 8 > (270LL << 20) && !std::getenv("RISVEC_COLSUM_NO_NT");
+            const dim3 g((unsigned)blocks), b(kSlabThreads);
+            if (s.n_veh <= 8) {
+                if (nt) hipLaunchKernelGGL((k_colsum_slab<8, true>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+                else hipLaunchKernelGGL((k_colsum_slab<8, false>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+            } else {
+                if (nt) hipLaunchKernelGGL((k_colsum_slab<16, true>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+                else hipLaunchKernelGGL((k_colsum_slab<16, false>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+            }
             return hipGetLastError();
         }
     }

@@ -83,9 +83,20 @@ struct GainCore {
     }
 };
 
-template <int V, int M, int D, class Core>
+// float4 load with the non-temporal hint (global_load ... nt): for a stream far larger than the 256 MiB Infinity
+// Cache, allocating every line on its way through only evicts what somebody else could have reused
+__device__ __forceinline__ float4 ld_nt(const float4* p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
+// per_wave > 0: a wavefront owns the CONTIGUOUS groups [wid * per_wave, (wid + 1) * per_wave) -- it walks one
+// contiguous piece of h_r from start to end; per_wave = 0: groups wid, wid + nw, ... (the round-1 form).
+// NT: h_r / theta are read with the non-temporal hint.
+template <int V, int M, int D, class Core, bool NT = false>
 __global__ void __launch_bounds__(kBlock)
-k_step_fused_pipe(Dims d, typename Core::Params P, typename Core::Args A, int n_groups_total) {
+k_step_fused_pipe(Dims d, typename Core::Params P, typename Core::Args A, int n_groups_total, int per_wave) {
     using In = typename Core::In;
     using S = PipeShape<V, M>;
     constexpr int VP = S::VP, EPW = S::EPW, NP = S::NP, G = S::G, NIT = S::NIT, VPP = S::VPP;
@@ -127,25 +138,31 @@ k_step_fused_pipe(Dims d, typename Core::Params P, typename Core::Args A, int n_
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int p = gl + it * G;
-                u.h[pc][it] = (NP % G == 0 || p < NP) ? hb[lane_off + ((c * PC + pc) * VPP * NP + it * G)]
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4* __restrict__ src = hb + (lane_off + ((c * PC + pc) * VPP * NP + it * G));
+                u.h[pc][it] = (NP % G == 0 || p < NP) ? (NT ? ld_nt(src) : *src) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         if (c == 0) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int p = gl + it * G;
-                u.t[it] = (NP % G == 0 || p < NP) ? tb[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                u.t[it] = (NP % G == 0 || p < NP) ? (NT ? ld_nt(tb + p) : tb[p]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
 
-    int grp = wid;
+    // per_wave < 0 (experiment): the four wavefronts of a workgroup interleave over ONE contiguous range of
+    // 4 * |per_wave| groups
+    constexpr int WPB = kBlock / kWave;
+    const int stride = per_wave > 0 ? 1 : (per_wave < 0 ? WPB : nw);
+    int grp = per_wave > 0 ? wid * per_wave : (per_wave < 0 ? (wid / WPB) * (-per_wave * WPB) + (wid % WPB) : wid);
+    int grp_end = per_wave > 0 ? grp + per_wave : (per_wave < 0 ? (wid / WPB + 1) * (-per_wave * WPB) : n_groups_total);
+    grp_end = grp_end < n_groups_total ? grp_end : n_groups_total;
     // Fetch the kernel-argument pointers in the SAME scalar-load round trip as the exit condition: left alone, the
     // compiler loads n_groups_total first, waits, branches, and only then requests the pointers -- a second cold
     // scalar-cache miss (~0.35 us) in front of every wavefront's first HBM request.
-    RISVEC_ARGS_IN_ONE_TRIP("s"(A.h_r), "s"(A.theta), "s"(A.b), "s"(n_groups_total), "s"(d.E));
-    if (grp >= n_groups_total) return;                     // whole wave: no cross-lane op is skipped
+    RISVEC_ARGS_IN_ONE_TRIP("s"(A.h_r), "s"(A.theta), "s"(A.b), "s"(n_groups_total), "s"(per_wave), "s"(d.E));
+    if (grp >= grp_end) return;                            // whole wave: no cross-lane op is skipped
 #pragma unroll
     for (int ui = 0; ui < D; ++ui) load_unit(ring[ui], grp, ui);
     const int v_mine = lane % VP;
@@ -158,7 +175,7 @@ k_step_fused_pipe(Dims d, typename Core::Params P, typename Core::Args A, int n_
         // The prefetch is unconditional (straight-line code keeps the compiler's vmcnt
         // bookkeeping exact): a wave on its last group "prefetches" group 0 instead, which
         // every such wave shares, so those requests are served by L2 and cost no HBM traffic.
-        const int nxt = (g_cur + nw < n_groups_total) ? g_cur + nw : 0;
+        const int nxt = (g_cur + stride < grp_end) ? g_cur + stride : 0;
         const int e_mine = g_cur * EPW + lane / VP;
         const bool active = e_mine < d.E;
         // Take the wait for this group's per-lane inputs HERE (they were requested a whole
@@ -214,11 +231,11 @@ k_step_fused_pipe(Dims d, typename Core::Params P, typename Core::Args A, int n_
     In inA = Core::load(d, A, grp * EPW + lane / VP, v_mine, grp * EPW + lane / VP < d.E), inB;
     while (true) {
         do_group(grp, inA, inB);
-        grp += nw;
-        if (grp >= n_groups_total) break;
+        grp += stride;
+        if (grp >= grp_end) break;
         do_group(grp, inB, inA);
-        grp += nw;
-        if (grp >= n_groups_total) break;
+        grp += stride;
+        if (grp >= grp_end) break;
     }
 }
 
@@ -237,6 +254,11 @@ static int pipe_waves_per_cu() {
     return v;
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* s = std::getenv(name);
+    return s ? std::atoi(s) : dflt;
+}
+
 template <int V, int M, int D, class Core>
 static hipError_t launch_pipe(const RisVecState& s, const typename Core::Params& p, const typename Core::Args& a,
                               hipStream_t st) {
@@ -249,7 +271,20 @@ static hipError_t launch_pipe(const RisVecState& s, const typename Core::Params&
     const long long per_wave = (n_groups + want_waves - 1) / want_waves;
     want_waves = (n_groups + per_wave - 1) / per_wave;
     const unsigned grid = (unsigned)((want_waves + wpb - 1) / wpb);
-    hipLaunchKernelGGL((k_step_fused_pipe<V, M, D, Core>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_groups);
+    // Non-temporal h_r / theta loads once the per-step stream no longer fits the 256 MiB Infinity Cache.  Measured
+    // (same box, E x 8 x 64, us per step default / nt): 40 960 envs (188 MiB) 32.9 / 39.0, 57 344 (263 MiB) 46.0 / 53.8,
+    // 65 536 (288 MiB) 59.4 / 57.8, 262 144 (1.15 GiB) 245-250 / 221-223; 32 768 x 16 x 256 (1.1 GiB) with the BCD sweep
+    // 276-284 / 240-252 -- below the cache size the re-read of last step's lines is worth more than the hint, above it
+    // the hint is worth 10 %.  RISVEC_PIPE_NT = 0 / 1 force it off / on; RISVEC_PIPE_CHUNKED (1: contiguous group range
+    // per wavefront, 2: per workgroup) is an experiment that lost at every size but one (214 vs 222 us at 262 144 envs).
+    static const int chunked = env_int("RISVEC_PIPE_CHUNKED", 0);
+    static const int nt_mode = env_int("RISVEC_PIPE_NT", 2);              // 0 never, 1 always, 2 by stream size
+    static const long long nt_from = (long long)env_int("RISVEC_PIPE_NT_MB", 270) << 20;
+    const long long stream_bytes = (long long)s.n_envs * (8LL * V * M + 8LL * M);
+    const bool nt = nt_mode == 1 || (nt_mode == 2 && stream_bytes > nt_from);
+    const int pw = chunked == 1 ? (int)per_wave : (chunked == 2 ? -(int)per_wave : 0);
+    if (nt) hipLaunchKernelGGL((k_step_fused_pipe<V, M, D, Core, true>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_groups, pw);
+    else hipLaunchKernelGGL((k_step_fused_pipe<V, M, D, Core, false>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_groups, pw);
     return hipGetLastError();
 }
 

@@ -36,3 +36,58 @@ extern "C" int membench_copy(const void* src, void* dst, long long n_float4, int
     hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n_float4);
     return (int)hipGetLastError();
 }
+
+// ---- round 2: what is the ceiling for a RE-READ working set of the headline's size? ------------------------
+// variants: loads in flight per lane (U), chunked (a workgroup owns a contiguous chunk, as the fused kernel's
+// wavefronts own env groups) vs grid-strided, non-temporal loads.
+template <int U, bool CHUNK, bool NT>
+__global__ void __launch_bounds__(256)
+k_read2(const float4* __restrict__ src, long long n, float* __restrict__ sink) {
+    float4 acc[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) acc[k] = make_float4(0, 0, 0, 0);
+    long long i, end, step;
+    if (CHUNK) {
+        const long long per = (n + gridDim.x - 1) / gridDim.x;
+        i = (long long)blockIdx.x * per + threadIdx.x;
+        end = (long long)(blockIdx.x + 1) * per;
+        if (end > n) end = n;
+        step = 256;
+    } else {
+        i = (long long)blockIdx.x * 256 + threadIdx.x;
+        end = n;
+        step = (long long)gridDim.x * 256;
+    }
+    for (; i + (U - 1) * step < end; i += U * step) {
+        float4 x[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (NT) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + i + k * step));
+                x[k] = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                x[k] = src[i + k * step];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) { acc[k].x += x[k].x; acc[k].y += x[k].y; acc[k].z += x[k].z; acc[k].w += x[k].w; }
+    }
+    for (; i < end; i += step) { const float4 x = src[i]; acc[0].x += x.x; acc[0].y += x.y; acc[0].z += x.z; acc[0].w += x.w; }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < U; ++k) s += acc[k].x + acc[k].y + acc[k].z + acc[k].w;
+    sink[(long long)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+extern "C" int membench_read2(const void* src, long long n, void* sink, int blocks, int unroll, int chunk, int nt, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const float4* s = (const float4*)src;
+    float* k = (float*)sink;
+#define RB_CASE(U, C, N) if (unroll == U && chunk == C && nt == N) { hipLaunchKernelGGL((k_read2<U, C, N>), dim3(blocks), dim3(256), 0, st, s, n, k); return (int)hipGetLastError(); }
+    RB_CASE(4, false, false) RB_CASE(8, false, false) RB_CASE(16, false, false)
+    RB_CASE(4, true, false) RB_CASE(8, true, false) RB_CASE(16, true, false)
+    RB_CASE(4, false, true) RB_CASE(8, false, true) RB_CASE(8, true, true)
+#undef RB_CASE
+    return -1;
+}
