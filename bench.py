@@ -233,34 +233,46 @@ def measured_traffic(kernel_prefix: str):
 
 
 def yardstick_read(n_bytes: int, device) -> dict | None:
-    """What the memory system of THIS device delivers to the simplest possible kernel (a float4 read with a
-    running sum, tools/membench) on a buffer of the step's read size: the ceiling a streaming kernel can be held to."""
+    """What the memory system of THIS device delivers to the simplest possible kernels (float4 reads with a running
+    sum, tools/membench) on a buffer of the step's read size, re-read every launch like the step's h_r / theta: the best
+    of the round-1 grid-strided reader and the round-2 variants (a contiguous chunk per workgroup, 8 / 16 loads in flight
+    per lane, with and without the non-temporal hint) -- the ceiling a streaming kernel can be held to."""
     import ctypes as C
     path = os.path.join(ROOT, "tools", "membench", "libmembench.so")
     if not os.path.isfile(path):
         return None
     lib = C.CDLL(path)
     lib.membench_read.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p]
+    have2 = hasattr(lib, "membench_read2")
+    if have2:
+        lib.membench_read2.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     n4 = max(1, n_bytes // 16)
     src = torch.empty(n4 * 4, dtype=torch.float32, device=device).normal_()
-    best = None
     stream = torch.cuda.current_stream(device).cuda_stream
-    for blocks in (2048, 4096, 8192):
-        sink = torch.empty(blocks * 256, dtype=torch.float32, device=device)
-        for _ in range(20):
-            lib.membench_read(src.data_ptr(), n4, sink.data_ptr(), blocks, stream)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 200 if n_bytes < (1 << 30) else 40
-        torch.cuda.synchronize()
-        a.record()
-        for _ in range(n):
-            lib.membench_read(src.data_ptr(), n4, sink.data_ptr(), blocks, stream)
-        b.record()
-        torch.cuda.synchronize()
-        t = a.elapsed_time(b) * 1e-3 / n
-        if best is None or t < best:
-            best = t
-    return dict(kernel="tools/membench: float4 read + running sum", bytes=n4 * 16, us=best * 1e6, GBps=n4 * 16 / best / 1e9)
+    sink = torch.empty(8192 * 256, dtype=torch.float32, device=device)
+    cases = [("grid-strided, 4 loads in flight", lambda bl: lib.membench_read(src.data_ptr(), n4, sink.data_ptr(), bl, stream))]
+    if have2:
+        for u, ch, nt in ((8, 1, 0), (16, 1, 0), (16, 0, 0), (8, 1, 1)):
+            cases.append(("%s, %d loads in flight%s" % ("chunk per workgroup" if ch else "grid-strided", u, ", non-temporal" if nt else ""),
+                          lambda bl, u=u, ch=ch, nt=nt: lib.membench_read2(src.data_ptr(), n4, sink.data_ptr(), bl, u, ch, nt, stream)))
+    best = None
+    n = 100 if n_bytes < (1 << 30) else 20
+    for label, fn in cases:
+        for blocks in (1024, 2048, 4096):
+            for _ in range(10):
+                fn(blocks)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(n):
+                fn(blocks)
+            b.record()
+            torch.cuda.synchronize()
+            t = a.elapsed_time(b) * 1e-3 / n
+            if best is None or t < best[0]:
+                best = (t, "%s, %d workgroups" % (label, blocks))
+    return dict(kernel="tools/membench: float4 read + running sum (%s)" % best[1], bytes=n4 * 16, us=best[0] * 1e6,
+                GBps=n4 * 16 / best[0] / 1e9)
 
 
 # ---------------------------------------------------------------------------------------------- one measured case
@@ -455,7 +467,7 @@ class _Opts:
             setattr(self, k, v)
 
 
-def run_leg(name, E, V, M, mode, device, rank, world, steps, warmup, gather_every=0, multi=0):
+def run_leg(name, E, V, M, mode, device, rank, world, steps, warmup, gather_every=0, multi=0, yardstick=False):
     """A secondary workload measured in the same process with the same timing protocol."""
     start = rank * E
     case = Case(E, V, M, mode, device, rank, world, start, _Opts(multi=multi), gather_every)
@@ -474,6 +486,11 @@ def run_leg(name, E, V, M, mode, device, rank, world, steps, warmup, gather_ever
     if mode == "bcd":
         out["bcd_candidate_evals_per_s"] = E * world * steps / dt * M * 8
     case.close()
+    if yardstick and rank == 0:
+        y = yardstick_read((8 * V * M + 8 * M) * E, device)
+        if y:
+            out["yardstick"] = y
+            out["frac_of_yardstick"] = per_env * E / (kernel_ms * 1e-3) / 1e9 / y["GBps"]
     return out
 
 
@@ -639,7 +656,7 @@ def main() -> None:
     default_shape = (E, V, M, args.mode) == CONFIGS["c3"][:4] and not (args.noma or args.lean or args.steer or args.meter)
     if default_shape and not args.no_legs:
         if world == 1:
-            legs["hbm_only"] = run_leg("hbm_only", 262144, 8, 64, "fused", device, rank, world, 200, 30)
+            legs["hbm_only"] = run_leg("hbm_only", 262144, 8, 64, "fused", device, rank, world, 200, 30, yardstick=True)
             legs["c2"] = run_leg("c2", *CONFIGS["c2"][:4], device, rank, world, 2000, 200)
             legs["c2_multi_step"] = run_leg("c2", *CONFIGS["c2"][:4], device, rank, world, 3200, 320, multi=32)
             legs["c4_shard"] = run_leg("c4_shard", *CONFIGS["c4"][:4], device, rank, world, 2000, 200)
