@@ -682,7 +682,8 @@ hipError_t launch_colsum(const RisVecState& s, hipStream_t st) {
         const long long blocks = ((long long)s.n_envs + kWave - 1) / kWave;
         if (blocks < (1LL << 31)) {
             // h_r streams larger than the Infinity Cache are read with the non-temporal hint (see launch_pipe)
-            const bool nt = (long long)s.n_envs * s.n_veh * s.n_ris * 8 > (270LL << 20) && !std::getenv("RISVEC_COLSUM_NO_NT");
+            static const char* nt_env = std::getenv("RISVEC_COLSUM_NT");          // "0" / "1" force it off / on (tests, A/B)
+            const bool nt = nt_env ? nt_env[0] == '1' : (long long)s.n_envs * s.n_veh * s.n_ris * 8 > (270LL << 20);
             const dim3 g((unsigned)blocks), b(kSlabThreads);
             if (s.n_veh <= 8) {
                 if (nt) hipLaunchKernelGGL((k_colsum_slab<8, true>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);

@@ -234,6 +234,16 @@ inline int pick_group(int M, int vec, int VP) {
     return g;
 }
 
+// store of an output nobody reads again before the next kernel (experiment switch: non-temporal hint)
+template <class T>
+__device__ __forceinline__ void st_out(T* p, T v) {
+#ifdef RISVEC_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // Per-step extras of the multi-step launch (risvec_step_fused_multi): where this step's trajectory
 // record goes (pointers already offset to the step's slice; nullptr = not recorded) and whether the
 // env's own state / output tensors are written (only the last step of a launch needs to).
@@ -366,15 +376,16 @@ __device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams
     if constexpr (TRAJ) store_state = tj->store_state;
     if (active && store_state) {
         A.data_buf[idx] = Bn;
-        A.rate[idx] = rate;
-        A.data_t[idx] = data_t;
-        A.data_p[idx] = data_p;
-        A.reward[idx] = rew;
-        A.over_power[idx] = over_power;
+        st_out(A.rate + idx, rate);
+        st_out(A.data_t + idx, data_t);
+        st_out(A.data_p + idx, data_p);
+        st_out(A.reward + idx, rew);
+        st_out(A.over_power + idx, over_power);
         if (A.flags & RISVEC_STEP_OBS) {
             // marl_train_bcd.py:819-827 (element 3 = over_data/10 is always 0)
             float* o = A.obs + idx * 5;
-            o[0] = Bn * 0.1f; o[1] = data_t * 0.1f; o[2] = data_p * 0.1f; o[3] = 0.f; o[4] = rate * 0.05f;
+            st_out(o + 0, Bn * 0.1f); st_out(o + 1, data_t * 0.1f); st_out(o + 2, data_p * 0.1f); st_out(o + 3, 0.f);
+            st_out(o + 4, rate * 0.05f);
         }
         if (A.flags & RISVEC_STEP_POWER_W) {
             const float inv_tf = __builtin_amdgcn_rcpf(tf);

@@ -433,3 +433,45 @@ def test_facade_takes_the_group_lists_the_reference_takes():
     a = np.asarray(r[3]).copy()
     env.step(g["action"][0], [[0], [1]], arrivals=g["arrivals"][0])
     assert np.array_equal(np.asarray(r[3]), a)
+
+
+# ---------------------------------------------------------------------------- non-temporal load variants
+@pytest.mark.parametrize("E,V,M", [(2100, 8, 64), (300, 16, 256), (1500, 8, 36)])
+def test_non_temporal_variants_are_bit_identical(E, V, M):
+    """Above ~270 MiB per step the software pipeline (MARL / SARL / gain cores) and k_colsum_slab read h_r / theta with
+    the non-temporal hint; the hint must not change a bit.  The switch is read once per process, so a child process
+    forces it on at a small size (RISVEC_PIPE_NT=1, RISVEC_COLSUM_NT=1, RISVEC_LAT_MAX_ENVS=0 to stay in the pipeline)."""
+    import subprocess
+    import sys
+    import tempfile
+    rng = np.random.default_rng(E + M)
+    action, partner, ng, arrivals = random_step_inputs(E, V, rng)
+    phase = rng.uniform(0, 2 * np.pi, (E, M)).astype(np.float32)
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from tests.test_entry_points_hip import _rollout_env, cpu\n"
+        "z = np.load(sys.argv[1])\n"
+        "env = _rollout_env(%d, %d, %d)\n"
+        "out = {}\n"
+        "env.rebuild_colsum(); out['c_col'] = cpu(env.tensors['c_col'])\n"
+        "env.compute_parms(); env.optimize_phase_shift(); env.update_channel_gains(); out['gain_only'] = cpu(env.tensors['gain'])\n"
+        "for _ in range(2):\n"
+        "    env.step(z['action'].astype(np.float32), z['partner'].astype(np.int32), z['ng'].astype(np.int32), z['arrivals'].astype(np.int32), fused=True)\n"
+        "for k in ('gain', 'reward', 'data_buf', 'metrics', 'obs', 'theta'): out[k] = cpu(env.tensors[k])\n"
+        "env.sarl_step(np.clip(z['action'], 0, 1).astype(np.float32), z['phase'], z['arrivals'].astype(np.int32))\n"
+        "for k in ('gain', 'reward', 'data_buf'): out['sarl_' + k] = cpu(env.tensors[k])\n"
+        "np.savez(sys.argv[2], **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), E, V, M)
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), action=action, partner=partner, ng=ng, arrivals=arrivals, phase=phase)
+        outs = []
+        for name, extra in (("default", dict(RISVEC_PIPE_NT="0", RISVEC_COLSUM_NT="0")), ("nt", dict(RISVEC_PIPE_NT="1", RISVEC_COLSUM_NT="1"))):
+            e = dict(os.environ, RISVEC_LAT_MAX_ENVS="0", **extra)
+            dst = os.path.join(tmp, name + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), dst], env=e, capture_output=True, text=True,
+                               timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(np.load(dst))
+        assert set(outs[0].files) == set(outs[1].files) and len(outs[0].files) == 11
+        for k in outs[0].files:
+            assert np.array_equal(outs[0][k], outs[1][k]), k
