@@ -42,6 +42,20 @@ template <int VEC> __device__ __forceinline__ typename Pack<VEC>::F ones();
 template <> __device__ __forceinline__ float ones<1>() { return 1.0f; }
 template <> __device__ __forceinline__ float4 ones<4>() { return make_float4(1.0f, 1.0f, 1.0f, 1.0f); }
 
+// The ring is write-once data (a learner samples it much later): its stores carry the non-temporal hint so that
+// 30 MB per step of transitions do not push the env's h_r / theta working set out of the Infinity Cache.
+#ifndef RISVEC_RING_DEFAULT_POLICY
+__device__ __forceinline__ void ring_st(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void ring_st(float4* p, float4 v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+#else
+__device__ __forceinline__ void ring_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void ring_st(float4* p, float4 v) { *p = v; }
+#endif
+
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_replay_store(StoreArgs A) {
@@ -67,11 +81,11 @@ k_replay_store(StoreArgs A) {
     if (gid < units) {
         const long long w = gid * VEC;
         if (w < b0) {
-            *reinterpret_cast<F*>(rb.state_memory + dest(w, S)) = *reinterpret_cast<const F*>(A.state + w);
+            ring_st(reinterpret_cast<F*>(rb.state_memory + dest(w, S)), *reinterpret_cast<const F*>(A.state + w));
         } else if (w < b1) {
             const long long g = w - b0;
             if (A.action) {
-                *reinterpret_cast<F*>(rb.action_memory + dest(g, Ac)) = *reinterpret_cast<const F*>(A.action + g);
+                ring_st(reinterpret_cast<F*>(rb.action_memory + dest(g, Ac)), *reinterpret_cast<const F*>(A.action + g));
             } else {
                 // the row risvec_marshal_actions would have built (TRAIN:1386-1390, 1776-1784), straight from the policy
                 // outputs: per agent [probs_i with zero diagonal | raw power_i]
@@ -84,20 +98,20 @@ k_replay_store(StoreArgs A) {
                     o[c] = k < Vn ? (k == v ? 0.0f : A.probs[(size_t)ev * Vn + k]) : A.power_raw[(size_t)ev * 2 + (k - Vn)];
                     if (++k == W) { k = 0; ++ev; v = v + 1 == Vn ? 0 : v + 1; }
                 }
-                *reinterpret_cast<F*>(rb.action_memory + dest(g, Ac)) = *reinterpret_cast<const F*>(o);
+                ring_st(reinterpret_cast<F*>(rb.action_memory + dest(g, Ac)), *reinterpret_cast<const F*>(o));
             }
         } else if (w < b2) {
             const long long g = w - b1;
-            *reinterpret_cast<F*>(rb.reward_local_memory + dest(g, L)) = *reinterpret_cast<const F*>(A.reward_l + g);
+            ring_st(reinterpret_cast<F*>(rb.reward_local_memory + dest(g, L)), *reinterpret_cast<const F*>(A.reward_l + g));
         } else if (w < b3) {
             const long long g = w - b2;
             const F v = *reinterpret_cast<const F*>(A.state_ + g);
-            *reinterpret_cast<F*>(rb.new_state_memory + dest(g, S)) = v;
+            ring_st(reinterpret_cast<F*>(rb.new_state_memory + dest(g, S)), v);
             if (A.carry) *reinterpret_cast<F*>(A.carry + g) = v;      // next step's `state`, for free
         } else {
             const long long g = w - b3;
-            *reinterpret_cast<F*>(rb.mask_memory + dest(g, M)) =
-                A.mask ? widen<VEC>(*reinterpret_cast<const U*>(A.mask + g)) : ones<VEC>();    // TRAIN:1786-1789
+            ring_st(reinterpret_cast<F*>(rb.mask_memory + dest(g, M)),
+                    A.mask ? widen<VEC>(*reinterpret_cast<const U*>(A.mask + g)) : ones<VEC>());    // TRAIN:1786-1789
         }
         return;
     }
