@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(kBlock)
 k_step(Dims d, RisVecParams P, StepArgs A) {
     RISVEC_ARGS_IN_ONE_TRIP("s"(d.E), "s"(d.V), "s"(A.flags), "s"(A.action), "s"(A.data_buf), "s"(A.partner), "s"(A.n_groups),
                             "s"(A.mec_q), "s"(A.gain), "s"(A.pl), "s"(A.arrivals));
+    RISVEC_ARGS_IN_ONE_TRIP(RISVEC_STEP_PARAMS(P));
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int e = (int)(t / VP), v = (int)(t % VP);
     const bool active = e < d.E && v < d.V;

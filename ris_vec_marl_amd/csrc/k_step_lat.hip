@@ -49,6 +49,11 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     // requested.  Surplus wavefronts run with every lane inactive; all their addresses are clamped to the last env.
     const int v_mine = lane % VP, e_mine = e0 + lane / VP;
     const bool active = (lane / VP) < EPWT && e_mine < d.E;
+    // step()'s scalar parameters with the pointers, in the kernel's first scalar round trip -- where one or two envs per
+    // wavefront make the kernel a pure latency chain (same box, interleaved: configs[1] 5.09 -> 4.83 us).  With four
+    // envs per wavefront the same lines cost more at the front than they save inside step() (the configs[3] shard:
+    // 7.27 -> 7.68 us), and the T-step launch pays for them once per T steps either way.
+    if constexpr (!MULTI && EPWT <= 2) RISVEC_ARGS_IN_ONE_TRIP(RISVEC_STEP_PARAMS(P));
 
     // step() inputs first: they are used last, and loads return in issue order
     StepIn in = load_step_in(d, A, e_mine, v_mine, active);
@@ -57,14 +62,23 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(A.theta);
     const float4* __restrict__ b4 = reinterpret_cast<const float4*>(A.b);
     const int e_last = d.E - 1;
-    const unsigned lane_off = (unsigned)(gv * NP + gl);
 
     float4 bq[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int p = gl + it * G;
-        bq[it] = p < NP ? b4[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 x = b4[p < NP ? p : NP - 1];
+        bq[it] = p < NP ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // ragged rows: lanes past the end re-read the row's last float4 (see k_step_pipe.hip) -- a skipped load made the
+    // compiler put `s_waitcnt vmcnt(0)` between the first env's loads and the second's: two round trips, not one
+    int pcl[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = gl + it * G;
+        pcl[it] = (NP % G == 0 || p < NP) ? p : NP - 1;
+    }
+    const unsigned row_off = (unsigned)(gv * NP);
     // Units are loaded in batches of up to 4 (all of them when the wavefront owns <= 4 envs: one memory
     // round trip); the multi-step form may own 64/VP envs, where the gain phase is amortised over the steps.
     if constexpr (STAMP) ts[1] = __builtin_amdgcn_s_memrealtime();
@@ -86,16 +100,13 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
             for (int pc = 0; pc < PC; ++pc) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    const int p = gl + it * G;
-                    u[k].h[pc][it] = (NP % G == 0 || p < NP) ? hb[lane_off + ((c * PC + pc) * VPP * NP + it * G)]
-                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                    u[k].h[pc][it] = hb[row_off + (unsigned)pcl[it] + ((c * PC + pc) * VPP * NP)];
                 }
             }
             if (c == 0) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    const int p = gl + it * G;
-                    u[k].t[it] = (NP % G == 0 || p < NP) ? tb[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    u[k].t[it] = tb[pcl[it]];
                 }
             }
         }

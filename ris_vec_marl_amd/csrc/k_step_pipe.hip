@@ -113,14 +113,26 @@ k_step_fused_pipe(Dims d, typename Core::Params P, typename Core::Args A, int n_
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(A.theta);
     const float4* __restrict__ b4 = reinterpret_cast<const float4*>(A.b);
     const int e_last = d.E - 1;
-    const unsigned lane_off = (unsigned)(gv * NP + gl);      // lane's float4 offset inside an env's h_r block
-
     float4 bq[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int p = gl + it * G;
-        bq[it] = p < NP ? b4[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 x = b4[p < NP ? p : NP - 1];
+        bq[it] = p < NP ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // Ragged rows (NP % G != 0, i.e. M = 36 / 40: 18 / 20 float4 on 32 lanes): the lanes past the end of a row RE-READ
+    // its last float4 instead of skipping the load.  A skipped load is a branch around the request with a zero fill
+    // behind it, and the compiler can only order that fill against the loads in flight with `s_waitcnt vmcnt(0)` --
+    // every unit then drains the whole ring (16 full drains per group in the M = 36 kernel, no counted wait left).
+    // The re-read element shares its cache line with the row's last lane (no extra HBM traffic), and what those
+    // lanes add to the sums is an exact +0: their b[m] is zero, so w0 / w1 are (signed) zeros, and +0 + (h * -0) = +0.
+    int pcl[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = gl + it * G;
+        pcl[it] = (NP % G == 0 || p < NP) ? p : NP - 1;
+    }
+    const unsigned row_off = (unsigned)(gv * NP);
 
     using U = Unit<PC, NIT>;
     U ring[D];
@@ -137,16 +149,14 @@ k_step_fused_pipe(Dims d, typename Core::Params P, typename Core::Args A, int n_
         for (int pc = 0; pc < PC; ++pc) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int p = gl + it * G;
-                const float4* __restrict__ src = hb + (lane_off + ((c * PC + pc) * VPP * NP + it * G));
-                u.h[pc][it] = (NP % G == 0 || p < NP) ? (NT ? ld_nt(src) : *src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4* __restrict__ src = hb + (row_off + (unsigned)pcl[it] + ((c * PC + pc) * VPP * NP));
+                u.h[pc][it] = NT ? ld_nt(src) : *src;
             }
         }
         if (c == 0) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int p = gl + it * G;
-                u.t[it] = (NP % G == 0 || p < NP) ? (NT ? ld_nt(tb + p) : tb[p]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                u.t[it] = NT ? ld_nt(tb + pcl[it]) : tb[pcl[it]];
             }
         }
     };

@@ -9,6 +9,20 @@
 
 namespace risvec {
 
+// Every RisVecParams field step() reads, as operands for RISVEC_ARGS_IN_ONE_TRIP.  RisVecParams sits at the front of
+// the kernel-argument segment and these fields span three of its 64-byte lines; left alone the compiler loads each
+// one right before its first use inside step(), and the first touch of a line is a cold scalar-cache miss (~0.3 us)
+// on the critical path of a kernel that lives 4-6 us (seen in the ISA of k_step_fused_lat<8,36,2>: `s_load_dword
+// .. 0x54` / `.. 0x68` each followed by `s_waitcnt lgkmcnt(0)` in the middle of the arithmetic).  Named here they
+// travel with the pointers, in the one round trip every wavefront has to wait for anyway.
+#define RISVEC_STEP_PARAMS(P)                                                                                       \
+    "s"((P).bandwidth_mhz), "s"((P).noise_power), "s"((P).p_max), "s"((P).power_scale), "s"((P).qos_enable),          \
+    "s"((P).r_min_bpshz), "s"((P).d_max_s), "s"((P).qos_penalty), "s"((P).time_fast), "s"((P).k_cpu),                 \
+    "s"((P).f_local_max), "s"((P).f_edge_max), "s"((P).cycles_per_bit), "s"((P).cpu_share_floor), "s"((P).w_d),       \
+    "s"((P).w_e), "s"((P).reward_clip), "s"((P).poisson_cdf[0]), "s"((P).poisson_cdf[1]), "s"((P).poisson_cdf[2]),    \
+    "s"((P).poisson_cdf[3]), "s"((P).poisson_cdf[4]), "s"((P).poisson_cdf[5]), "s"((P).poisson_cdf[6]),               \
+    "s"((P).poisson_cdf[7])
+
 struct StepArgs {
     const float* action;
     const int32_t* partner;

@@ -713,7 +713,8 @@ def test_trajectory_through_facade():
             tol_b = tol_a + np.abs(o_dev["reward"][0] - o_ref["reward"][0])
             assert (np.abs(r_dev - g["reward"][i]) <= tol_b)[~excl_r].all(), i
             if (~excl_r).any():
-                record("trajectory reward rel err vs reference", np.max((np.abs(r_dev - g["reward"][i]) / np.abs(g["reward"][i]))[~excl_r]))
+                record("trajectory reward rel err vs reference",
+                       np.max((np.abs(r_dev - g["reward"][i]) / np.maximum(np.abs(g["reward"][i]), 1e-30))[~excl_r]))
             assert (np.abs(np.asarray(r[2]) - o_dev["data_buf"][0]) <= RT * o_dev["data_buf"][0] + 4e-7 * kb)[~excl_all].all()
             n_excl += int(excl_r.sum()); n_tot += V
             prev, prev_excl = (o_ref, o_dev), excl_all
