@@ -90,12 +90,17 @@ __device__ __forceinline__ bool noma_pre_env(const NomaArgs& A, int env, int& fl
     const RisVecNomaParams& P = A.P;
     // every load of the frozen path up front: one memory round trip instead of five dependent ones (a frozen
     // step is nothing but this function, so its latency IS the step's cost)
+    // (the two optional inputs select their ADDRESS, not the load: a load under `if (pointer)` is merged with the
+    // block that consumes it, and the loads behind it then wait for that block -- three round trips instead of one)
+    const float* prev_p = A.prev_global ? A.prev_global + (long long)env * A.prev_stride
+                                        : reinterpret_cast<const float*>(A.ns.pending + env);
+    const float* u_p = A.u_unstick ? A.u_unstick + env : reinterpret_cast<const float*>(A.ns.pending + env);
     int flags = A.ns.flags[env];
     double last = A.ns.last_global[env], best = A.ns.best_global[env];
-    const float prev = A.prev_global ? A.prev_global[(long long)env * A.prev_stride] : 0.0f;
+    const float prev = *prev_p;
     const int pend = A.ns.pending[env];
     const int n_groups = A.ns.n_groups[env];
-    const float u_in = A.u_unstick ? A.u_unstick[env] : 0.0f;
+    const float u_in = *u_p;
     if (A.prev_global) {                               // TRAIN:1618-1623, for the step that just ran
         const double g = (double)prev;
         if (!(flags & RISVEC_NOMA_HAS_LAST)) best = g;
@@ -307,12 +312,28 @@ k_noma_group(NomaArgs A) {
     int ei[EPL], ej[EPL];                              // this lane's matrix entries
     bool ein[EPL];
     bool tables_ready = false;
-    for (int e0 = blockIdx.x * kEnvsPerWave; e0 < A.ns.n_envs; e0 += gridDim.x * kEnvsPerWave) {
-    int my_flags = 0;
-    bool my_solve = false;
-    if (lane < kEnvsPerWave && e0 + lane < A.ns.n_envs) my_solve = noma_pre_env(A, e0 + lane, my_flags);
-    unsigned todo = (unsigned)__ballot(my_solve);
-    if (todo == 0) continue;                           // the common case: all 8 envs frozen
+    // The common case -- a wavefront whose (only) env group is frozen -- is decided and LEAVES here, in front of the loop.
+    // Whatever the solve path keeps loop-invariant (the Philox key schedule of the unstick draw, comparisons of its
+    // parameters, the spills they cause: ~280 instructions and eight scalar waits in the ISA) is hoisted into the
+    // loop's preheader, and with the check inside the loop that preheader ran before every frozen step's first load.
+    const int e_first = blockIdx.x * kEnvsPerWave;
+    if (e_first >= A.ns.n_envs) return;
+    int flags_first = 0;
+    bool solve_first = false;
+    if (lane < kEnvsPerWave && e_first + lane < A.ns.n_envs) solve_first = noma_pre_env(A, e_first + lane, flags_first);
+    const unsigned todo_first = (unsigned)__ballot(solve_first);
+    if (todo_first == 0 && (long long)e_first + (long long)gridDim.x * kEnvsPerWave >= A.ns.n_envs) return;
+    for (int e0 = e_first; e0 < A.ns.n_envs; e0 += gridDim.x * kEnvsPerWave) {
+    int my_flags = flags_first;
+    bool my_solve = solve_first;
+    unsigned todo = todo_first;
+    if (e0 != e_first) {
+        my_flags = 0;
+        my_solve = false;
+        if (lane < kEnvsPerWave && e0 + lane < A.ns.n_envs) my_solve = noma_pre_env(A, e0 + lane, my_flags);
+        todo = (unsigned)__ballot(my_solve);
+    }
+    if (todo == 0) continue;                           // all of the group's envs frozen
     if (!tables_ready) {
     tables_ready = true;
     // Only the (rare) wavefronts that solve anything need the tables below; the opaque move keeps the compiler
