@@ -94,8 +94,12 @@ k_replay_store(StoreArgs A) {
                 // one 32-bit division per lane (n * Ac < 2^32 is checked by the launcher), then walk the VEC words
                 unsigned ev = (unsigned)g / W, k = (unsigned)g - ev * W, v = ev % Vn;
 #pragma unroll
+                // the ADDRESS is selected, not the load: VEC independent requests and one wait (a load per branch of the
+                // select made VEC dependent memory round trips for a third of the kernel's lanes)
                 for (int c = 0; c < VEC; ++c) {
-                    o[c] = k < Vn ? (k == v ? 0.0f : A.probs[(size_t)ev * Vn + k]) : A.power_raw[(size_t)ev * 2 + (k - Vn)];
+                    const float* src = k < Vn ? A.probs + ((size_t)ev * Vn + k) : A.power_raw + ((size_t)ev * 2 + (k - Vn));
+                    const float x = *src;
+                    o[c] = k == v ? 0.0f : x;                  // k == v only happens inside the probs part (v < Vn)
                     if (++k == W) { k = 0; ++ev; v = v + 1 == Vn ? 0 : v + 1; }
                 }
                 ring_st(reinterpret_cast<F*>(rb.action_memory + dest(g, Ac)), *reinterpret_cast<const F*>(o));
