@@ -51,6 +51,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_replay_$TAG -o trace -- python3 $R/bench.py --replay --steps 500 --warmup 100 --no-cpu-baseline > $OUT/prof_replay_$TAG.log 2>&1
 cd $R
 python tools/sweep_stamps.py 32768 16 256 > $OUT/sweep_stamps_$TAG.json 2>/dev/null; cat $OUT/sweep_stamps_$TAG.json
+timeout -k 10 200 python tools/lat_stamps.py > $OUT/lat_stamps_$TAG.json 2>/dev/null; cat $OUT/lat_stamps_$TAG.json
 echo "== streaming yardstick" | tee -a $OUT/round_$TAG.log
 timeout -k 10 300 python tools/membench.py > $OUT/membench_$TAG.jsonl 2>/dev/null; cat $OUT/membench_$TAG.jsonl
 echo "== 2-rank rehearsal on one GPU (gloo for the collective; RCCL needs one GPU per rank)" | tee -a $OUT/round_$TAG.log
