@@ -452,8 +452,8 @@ class Case:
         lat = (self.V, self.M) in ((8, 64), (8, 36), (8, 40), (4, 16))          # csrc/k_step_lat.hip
         if self.mode == "fused" and lat and getattr(self.opts, "multi", 0) > 1:
             return "k_step_fused_lat<%d,%d,..,MULTI> (T-step launch)" % (self.V, self.M)
-        if self.mode == "fused" and lat and self.E <= int(os.environ.get("RISVEC_LAT_MAX_ENVS", "10240")):
-            return "k_step_fused_lat<%d,%d,..> (latency-shaped: small batch)" % (self.V, self.M)
+        if self.mode == "fused" and lat and self.E <= int(os.environ.get("RISVEC_LAT_MAX_ENVS", "24576")):
+            return "k_step_fused_lat<%d,%d,..> (latency-shaped: up to 24 576 envs)" % (self.V, self.M)
         k = "k_step_fused_pipe<%d,%d,..>" % (self.V, self.M) if pipe else "k_step_fused<..>"
         return {"fused": k.replace("..>", "..,MarlCore>") if pipe else k, "cached": "k_step",
                 "bcd": "k_bcd_sweep + " + k, "sarl": "k_set_phase + " + k.replace("..>", "..,SarlCore>")}[self.mode]

@@ -242,14 +242,19 @@ static hipError_t dispatch_lat(const RisVecState& s, const RisVecParams& p, cons
     return hipErrorNotSupported;
 }
 
-// Single step, small batch: taken instead of the software pipeline when the pipeline could not even give
-// every CU 8 wavefronts of 64/VP envs (n_envs < 8 CUs x 64/VP x ...); hipErrorNotSupported otherwise.
+// Single step, small and medium batches: taken instead of the software pipeline up to 24 576 envs.  Re-measured after
+// the ragged-row fix (tools/gpu_crossover.sh, profiles/r02t_lat_vs_pipe.txt; us per step, this kernel / pipeline):
+// 8 192 x 8 x 64  7.3 / 9.4, 12 288  11.5 / 12.5, 16 384  15.7 / 15.2, 20 480  17.9 / 18.7, 24 576  21.2 / 21.1,
+// 32 768  27.5 / 26.9;  M = 36: 8 192  5.7 / 6.5, 18 432  11.9 / 13.8, 32 768  18.0 / 18.4.  Four envs per wavefront with
+// every request up front keep up with the pipeline for as long as the batch is a few wavefronts per SIMD, and the
+// hardware dispatcher balances 4-env wavefronts better than the pipeline's fixed 2 048 wavefronts balance env groups
+// (18 432 envs = 2 304 groups = 1 152 wavefronts of two).
 hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
     const int vp = pow2_ceil(s.n_veh);
     const int epw = kWave / vp;
     static const long long limit = [] {                        // envs below which the latency shape wins
         const char* e = std::getenv("RISVEC_LAT_MAX_ENVS");
-        return e ? std::atoll(e) : 10240LL;
+        return e ? std::atoll(e) : 24576LL;
     }();
     if ((long long)s.n_envs > limit) return hipErrorNotSupported;
     const int epwt = lat_epwt(s.n_envs, epw);
