@@ -361,13 +361,14 @@ class Case:
             sp = SarlParams()
             launch = lambda: env.sarl_step(action, phase, None, sp, obs=full)       # noqa: E731
         elif getattr(opts, "multi", 0) > 1:
-            if mode != "fused" or opts.noma or opts.meter or opts.steer:
-                raise SystemExit("--multi T is the T-step launch of the fused gains+step path (no --noma/--meter/--steer)")
+            if mode not in ("fused", "cached") or opts.noma or opts.meter or opts.steer:
+                raise SystemExit("--multi T is the T-step launch of the fused gains+step path, or with --mode cached of the "
+                                 "step on cached gains (no --noma/--meter/--steer)")
             T = int(opts.multi)
             actions = torch.from_numpy(rng.uniform(0, 1, (T, E, 2, V)).astype(np.float32)).to(device)
             traj = dict(reward=torch.empty(T, E, V, device=device), obs=torch.empty(T, E, V, 5, device=device),
                         metrics=torch.empty(T, E, 16, device=device)) if full else {}
-            launch = env.bind_step_many(actions, partner, n_groups, None, metrics=full, obs=full, out=traj)
+            launch = env.bind_step_many(actions, partner, n_groups, None, metrics=full, obs=full, out=traj, fused=fused)
             self.multi = T
         else:
             launch = env.bind_step(power_raw if direct else action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full,
@@ -452,6 +453,10 @@ class Case:
         lat = (self.V, self.M) in ((8, 64), (8, 36), (8, 40), (4, 16))          # csrc/k_step_lat.hip
         if self.mode == "fused" and lat and getattr(self.opts, "multi", 0) > 1:
             return "k_step_fused_lat<%d,%d,..,MULTI> (T-step launch)" % (self.V, self.M)
+        if self.mode == "cached" and getattr(self.opts, "multi", 0) > 1:
+            return "k_step_multi (T-step launch on cached gains)"
+        if self.mode == "fused" and getattr(self.opts, "multi", 0) > 1:
+            return "k_step_fused<..> once + k_step_multi (T-step launch, shape without a compile-time fused kernel)"
         if self.mode == "fused" and lat and self.E <= int(os.environ.get("RISVEC_LAT_MAX_ENVS", "24576")):
             return "k_step_fused_lat<%d,%d,..> (latency-shaped: up to 24 576 envs)" % (self.V, self.M)
         k = "k_step_fused_pipe<%d,%d,..>" % (self.V, self.M) if pipe else "k_step_fused<..>"

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 12
+#define RISVEC_ABI_VERSION 13
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -304,6 +304,15 @@ int risvec_step_fused_multi(const RisVecState *s, const RisVecParams *p, int32_t
                             const int32_t *partner, const int32_t *n_groups, const int32_t *arrivals,
                             uint64_t seed, uint32_t counter, uint32_t flags, const RisVecTraj *traj,
                             risvec_stream_t stream);
+
+/* The same on the CACHED gains (state.gain as risvec_gain / a fused step left it): exactly `n_steps` consecutive
+ * risvec_step calls in one launch, for any shape -- the reference driver's own cadence, step() every step and the
+ * channel gains only every K_STEPS_FOR_RIS_OPTIMIZATION = 100 steps (marl_train_bcd.py:1304-1611, 1307-1309).
+ * Arguments as risvec_step_fused_multi; h_r / theta are not read. */
+int risvec_step_multi(const RisVecState *s, const RisVecParams *p, int32_t n_steps, const float *actions,
+                      const int32_t *partner, const int32_t *n_groups, const int32_t *arrivals,
+                      uint64_t seed, uint32_t counter, uint32_t flags, const RisVecTraj *traj,
+                      risvec_stream_t stream);
 
 /* SARL variant: Simulation-SARL/Environment.py step(action_power, action_phase)
  * SENV:321-359 for every env: get_next_phase (theta = exp(j*action_phase), action_phase [E,M]

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -148,6 +148,8 @@ _PROTOS = {
                                     _FP, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
     "risvec_step_fused_multi": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), C.c_int32, _FP, _FP, _FP, _FP,
                                           C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(RisVecTraj), _FP]),
+    "risvec_step_multi": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), C.c_int32, _FP, _FP, _FP, _FP,
+                                    C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(RisVecTraj), _FP]),
     "risvec_sarl_step": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecSarlParams), _FP, _FP, _FP,
                                    C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
     "risvec_step_fused_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP,

@@ -54,6 +54,24 @@ k_step(Dims d, RisVecParams P, StepArgs A) {
     step_core<VP, false, true>(d, P, A, e, v, active, g, in);
 }
 
+// K4 over T steps: the driver's own cadence (marl_train_bcd.py:1304-1611: step() every step, the channel gains only every
+// K_STEPS_FOR_RIS_OPTIMIZATION = 100 steps) in ONE launch -- n_steps consecutive step() calls on the cached gains, for
+// any shape.  A lane owns one (env, vehicle) for the whole launch; the env's queues stay in registers, every step's
+// records go to their slice of the trajectory buffers, the env's own tensors receive the last step's outputs:
+// bit-identical to n_steps launches of k_step.
+template <int VP>
+__global__ void __launch_bounds__(kBlock)
+k_step_multi(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ) {
+    RISVEC_ARGS_IN_ONE_TRIP("s"(d.E), "s"(d.V), "s"(A.flags), "s"(A.action), "s"(A.data_buf), "s"(A.partner), "s"(A.n_groups),
+                            "s"(A.mec_q), "s"(A.gain), "s"(A.pl), "s"(A.arrivals), "s"(n_steps));
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int e = (int)(t / VP), v = (int)(t % VP);
+    const bool active = e < d.E && v < d.V;
+    const StepIn in = load_step_in(d, A, e, v, active);
+    const float g = active ? A.gain[(long long)e * d.V + v] : 0.f;
+    multi_step_loop<VP>(d, P, A, TJ, e, v, active, g, in, n_steps);
+}
+
 // compute_data_rate as its own entry point (ENV:331-372)
 template <int VP>
 __global__ void __launch_bounds__(kBlock)
@@ -293,6 +311,30 @@ hipError_t launch_step(const RisVecState& s, const RisVecParams& p, const float*
         case 16: return launch_step_vp<16>(s, p, a, fused, st);
         case 32: return launch_step_vp<32>(s, p, a, fused, st);
         case 64: return launch_step_vp<64>(s, p, a, fused, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int VP>
+static hipError_t launch_step_multi_vp(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                                       const RisVecTraj& tj, hipStream_t st) {
+    const long long threads = (long long)s.n_envs * VP;
+    const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((k_step_multi<VP>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_steps, tj);
+    return hipGetLastError();
+}
+
+hipError_t launch_step_multi(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                             const RisVecTraj* traj, hipStream_t st) {
+    const RisVecTraj tj = traj ? *traj : RisVecTraj{nullptr, nullptr, nullptr};
+    switch (pow2_ceil(s.n_veh)) {
+        case 1: return launch_step_multi_vp<1>(s, p, a, n_steps, tj, st);
+        case 2: return launch_step_multi_vp<2>(s, p, a, n_steps, tj, st);
+        case 4: return launch_step_multi_vp<4>(s, p, a, n_steps, tj, st);
+        case 8: return launch_step_multi_vp<8>(s, p, a, n_steps, tj, st);
+        case 16: return launch_step_multi_vp<16>(s, p, a, n_steps, tj, st);
+        case 32: return launch_step_multi_vp<32>(s, p, a, n_steps, tj, st);
+        case 64: return launch_step_multi_vp<64>(s, p, a, n_steps, tj, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -163,42 +163,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     } else if constexpr (!MULTI) {
         step_core<VP, false, true>(d, P, A, e_mine, v_mine, active, g, in);
     } else {
-        const long long ev = (long long)d.E * V;
-        const bool pol = (A.flags & RISVEC_STEP_POLICY_ACTION) != 0;
-        StepArgs At = A;
-        // Everything that moves from step to step ADVANCES by a stride (zero for an absent buffer: a null pointer stays
-        // null) instead of being recomputed as `p ? p + t * stride : nullptr` -- that was a branch around four scalar
-        // instructions per buffer per step, seven branches (and a kernel-argument reload) in a loop whose lone wavefront
-        // pays an instruction-fetch restart for each.
-        StepTraj tj;
-        tj.reward = TJ.reward; tj.obs = TJ.obs; tj.metrics = TJ.metrics;
-        const long long rw_stride = TJ.reward ? ev : 0, ob_stride = TJ.obs ? ev * 5 : 0;
-        const long long mt_stride = TJ.metrics ? (long long)d.E * RISVEC_METRICS : 0;
-        const long long ar_stride = A.arrivals ? ev : 0;
-        // this lane's word(s) of action[t]: [T, E, V, 2] (policy layout) or [T, E, 2, V]
-        const float* ap = A.action + (pol ? idx * 2 : (long long)e_mine * 2 * V + v_mine);
-        const long long a1_off = pol ? 1 : V;
-#pragma unroll 1
-        for (int t = 0; t < n_steps; ++t) {
-            // next step's action: in flight during this step's arithmetic (the last step re-reads its own)
-            if (t + 1 < n_steps) ap += 2 * ev;
-            float a0n = 0.f, a1n = 0.f;
-            if (active) {
-                a0n = ap[0];
-                a1n = ap[a1_off];
-            }
-            tj.store_state = t == n_steps - 1;
-            const StepCarry c = step_core<VP, true, true>(d, P, At, e_mine, v_mine, active, g, in, &tj);
-            At.counter += 1u;
-            At.arrivals += ar_stride;
-            tj.reward += rw_stride;
-            tj.obs += ob_stride;
-            tj.metrics += mt_stride;
-            in.B = c.B;
-            in.Q0 = c.Q;
-            in.a0 = a0n;
-            in.a1 = a1n;
-        }
+        multi_step_loop<VP>(d, P, A, TJ, e_mine, v_mine, active, g, in, n_steps);
     }
 }
 

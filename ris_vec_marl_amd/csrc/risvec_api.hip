@@ -290,25 +290,51 @@ int risvec_step_fused_multi(const RisVecState* s, const RisVecParams* p, int32_t
     const risvec::StepArgs a = risvec::make_step_args(*s, actions, partner, n_groups, arrivals, seed, counter, flags);
     const hipError_t err = risvec::launch_step_fused_multi(*s, *p, a, n_steps, traj, st);
     if (err != hipErrorNotSupported) return finish(fn, err);
-    // shapes without a compile-time kernel: the same thing as n_steps launches, records copied out after each
+    // Shapes without a compile-time fused kernel: step 0 through the single fused launch (gains computed and stored, its
+    // records copied out), steps 1 .. T-1 in ONE launch on those stored gains (h_r / theta cannot change inside the call,
+    // so they are the gains T fused launches would recompute): bit-identical to T risvec_step_fused calls.
     const long long ev = (long long)s->n_envs * s->n_veh;
-    for (int t = 0; t < n_steps; ++t) {
-        const hipError_t e1 = risvec::launch_step(*s, *p, actions + (long long)t * 2 * ev, partner, n_groups,
-                                                  arrivals ? arrivals + (long long)t * ev : nullptr, seed,
-                                                  counter + (uint32_t)t, flags, true, st);
-        if (e1 != hipSuccess) return finish(fn, e1);
-        if (traj) {
-            hipError_t e2 = hipSuccess;
-            if (traj->reward) e2 = hipMemcpyAsync(traj->reward + t * ev, s->reward, ev * 4, hipMemcpyDeviceToDevice, st);
-            if (e2 == hipSuccess && traj->obs && (flags & RISVEC_STEP_OBS))
-                e2 = hipMemcpyAsync(traj->obs + t * ev * 5, s->obs, ev * 20, hipMemcpyDeviceToDevice, st);
-            if (e2 == hipSuccess && traj->metrics)
-                e2 = hipMemcpyAsync(traj->metrics + (long long)t * s->n_envs * RISVEC_METRICS, s->metrics,
-                                    (size_t)s->n_envs * RISVEC_METRICS * 4, hipMemcpyDeviceToDevice, st);
-            if (e2 != hipSuccess) return finish(fn, e2);
-        }
+    const hipError_t e1 = risvec::launch_step(*s, *p, actions, partner, n_groups, arrivals, seed, counter, flags, true, st);
+    if (e1 != hipSuccess) return finish(fn, e1);
+    if (traj) {
+        hipError_t e2 = hipSuccess;
+        if (traj->reward) e2 = hipMemcpyAsync(traj->reward, s->reward, ev * 4, hipMemcpyDeviceToDevice, st);
+        if (e2 == hipSuccess && traj->obs && (flags & RISVEC_STEP_OBS))
+            e2 = hipMemcpyAsync(traj->obs, s->obs, ev * 20, hipMemcpyDeviceToDevice, st);
+        if (e2 == hipSuccess && traj->metrics)
+            e2 = hipMemcpyAsync(traj->metrics, s->metrics, (size_t)s->n_envs * RISVEC_METRICS * 4, hipMemcpyDeviceToDevice, st);
+        if (e2 != hipSuccess) return finish(fn, e2);
     }
-    return RISVEC_OK;
+    if (n_steps == 1) return RISVEC_OK;
+    const risvec::StepArgs rest = risvec::make_step_args(*s, actions + 2 * ev, partner, n_groups,
+                                                         arrivals ? arrivals + ev : nullptr, seed, counter + 1u, flags);
+    RisVecTraj tj{nullptr, nullptr, nullptr};
+    if (traj) {
+        tj.reward = traj->reward ? traj->reward + ev : nullptr;
+        tj.obs = (traj->obs && (flags & RISVEC_STEP_OBS)) ? traj->obs + ev * 5 : nullptr;
+        tj.metrics = traj->metrics ? traj->metrics + (long long)s->n_envs * RISVEC_METRICS : nullptr;
+    }
+    return finish(fn, risvec::launch_step_multi(*s, *p, rest, n_steps - 1, &tj, st));
+}
+
+int risvec_step_multi(const RisVecState* s, const RisVecParams* p, int32_t n_steps, const float* actions,
+                      const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals, uint64_t seed,
+                      uint32_t counter, uint32_t flags, const RisVecTraj* traj, risvec_stream_t stream) {
+    const char* fn = "risvec_step_multi";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    if (n_steps < 1 || n_steps > (1 << 20)) return fail(RISVEC_ERR_ARG, "%s: n_steps=%d outside [1, 2^20]", fn, n_steps);
+    if (flags & (RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX | RISVEC_STEP_STEER))
+        return fail(RISVEC_ERR_ARG, "%s: the BCD / steering flags (0x%x) are not accepted by the multi-step launch", fn, flags);
+    if (int rc = check_step(fn, s, actions, partner, n_groups, arrivals, flags, false)) return rc;
+    if (traj) { OPT_PTR(traj->reward, "traj.reward"); OPT_PTR(traj->obs, "traj.obs"); OPT_PTR(traj->metrics, "traj.metrics"); }
+    const risvec::StepArgs a = risvec::make_step_args(*s, actions, partner, n_groups, arrivals, seed, counter, flags);
+    RisVecTraj tj{nullptr, nullptr, nullptr};
+    if (traj) {
+        tj = *traj;
+        if (!(flags & RISVEC_STEP_OBS)) tj.obs = nullptr;      // obs records need the obs flag, as in the fused form
+    }
+    return finish(fn, risvec::launch_step_multi(*s, *p, a, n_steps, &tj, (hipStream_t)stream));
 }
 
 int risvec_sarl_step(const RisVecState* s, const RisVecSarlParams* p, const float* action_power,

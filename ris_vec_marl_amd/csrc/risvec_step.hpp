@@ -514,5 +514,53 @@ hipError_t launch_gain_pipe(const RisVecState& s, hipStream_t st);
 hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st);
 hipError_t launch_step_fused_multi(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
                                    const RisVecTraj* traj, hipStream_t st);
+// n_steps consecutive steps on the CACHED gains in one launch, any shape (k_step.hip)
+hipError_t launch_step_multi(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                             const RisVecTraj* traj, hipStream_t st);
+
+// The step loop of a T-step launch (SURVEY 7 "launch latency"; the driver loop marl_train_bcd.py:1304-1611 between two
+// channel refreshes, groups frozen as inside an episode), shared by the fused form (k_step_fused_lat<.., MULTI>) and the
+// cached-gain form (k_step_multi): the wavefront keeps its envs' queues in registers and walks the steps.  `in` holds
+// step 0's inputs; actions[t + 1] is in flight during step t.  Everything that moves from step to step ADVANCES by a
+// stride (zero for an absent buffer: a null pointer stays null) instead of being recomputed as `p ? p + t * stride :
+// nullptr` -- that was a branch around four scalar instructions per buffer per step, seven branches (and a
+// kernel-argument reload) in a loop whose lone wavefront pays an instruction-fetch restart for each.
+template <int VP>
+__device__ __forceinline__ void multi_step_loop(const Dims& d, const RisVecParams& P, const StepArgs& A, const RisVecTraj& TJ,
+                                                int e, int v, bool active, float g, StepIn in, int n_steps) {
+    const int V = d.V;
+    const long long ev = (long long)d.E * V, idx = (long long)e * V + v;
+    const bool pol = (A.flags & RISVEC_STEP_POLICY_ACTION) != 0;
+    StepArgs At = A;
+    StepTraj tj;
+    tj.reward = TJ.reward; tj.obs = TJ.obs; tj.metrics = TJ.metrics;
+    const long long rw_stride = TJ.reward ? ev : 0, ob_stride = TJ.obs ? ev * 5 : 0;
+    const long long mt_stride = TJ.metrics ? (long long)d.E * RISVEC_METRICS : 0;
+    const long long ar_stride = A.arrivals ? ev : 0;
+    // this lane's word(s) of action[t]: [T, E, V, 2] (policy layout) or [T, E, 2, V]
+    const float* ap = A.action + (pol ? idx * 2 : (long long)e * 2 * V + v);
+    const long long a1_off = pol ? 1 : V;
+#pragma unroll 1
+    for (int t = 0; t < n_steps; ++t) {
+        // next step's action: in flight during this step's arithmetic (the last step re-reads its own)
+        if (t + 1 < n_steps) ap += 2 * ev;
+        float a0n = 0.f, a1n = 0.f;
+        if (active) {
+            a0n = ap[0];
+            a1n = ap[a1_off];
+        }
+        tj.store_state = t == n_steps - 1;
+        const StepCarry c = step_core<VP, true, true>(d, P, At, e, v, active, g, in, &tj);
+        At.counter += 1u;
+        At.arrivals += ar_stride;
+        tj.reward += rw_stride;
+        tj.obs += ob_stride;
+        tj.metrics += mt_stride;
+        in.B = c.B;
+        in.Q0 = c.Q;
+        in.a0 = a0n;
+        in.a1 = a1n;
+    }
+}
 
 }  // namespace risvec

@@ -404,7 +404,7 @@ class VecEnviron(ParamAttrs):
 
     def step_many(self, actions, partner, n_groups, arrivals=None, metrics: bool = True, power_w: bool = False,
                   obs: bool = True, policy_action: bool = False, record: Sequence[str] = ("reward", "obs", "metrics"),
-                  out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                  out: Optional[Dict[str, torch.Tensor]] = None, fused: bool = True) -> Dict[str, torch.Tensor]:
         """T consecutive fused `step()` calls in ONE launch (`risvec_step_fused_multi`): the driver's step loop
         marl_train_bcd.py:1304-1611 between two channel refreshes with the NOMA groups frozen, as they are
         inside an episode.  actions [T,E,2,V] float32 (or [T,E,V,2] with policy_action=True); partner / n_groups as
@@ -414,7 +414,9 @@ class VecEnviron(ParamAttrs):
         ("reward" [T,E,V], "obs" [T,E,V,5], "metrics" [T,E,16]) -- returned as a dict, written into `out`'s
         tensors when given.  h_r / theta cannot change inside the launch, so the gains are computed once and each
         env's queues stay in registers: this is the launch to use when a batched step is shorter than a kernel
-        launch (small E)."""
+        launch (small E).  fused=False (`risvec_step_multi`) is the same on the CACHED gains -- T `step(...,
+        fused=False)` calls, the reference driver's own cadence (gains only every 100 steps), any shape, h_r / theta
+        not read at all."""
         self._ensure_device()
         E, V = self.n_envs, self.n_veh
         a = torch.as_tensor(actions)
@@ -441,9 +443,9 @@ class VecEnviron(ParamAttrs):
         tj = N.RisVecTraj(_dev_ptr(rec.get("reward")), _dev_ptr(rec.get("obs")), _dev_ptr(rec.get("metrics")))
         flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
                  | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0))
-        N.check(N.load().risvec_step_fused_multi(C.byref(self._cstate), C.byref(self._p()), T, _dev_ptr(a), _dev_ptr(pt),
-                                                 _dev_ptr(ng), _dev_ptr(ar), self.seed, self._steps, flags, C.byref(tj),
-                                                 self._stream()))
+        fn = N.load().risvec_step_fused_multi if fused else N.load().risvec_step_multi
+        N.check(fn(C.byref(self._cstate), C.byref(self._p()), T, _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng), _dev_ptr(ar),
+                   self.seed, self._steps, flags, C.byref(tj), self._stream()))
         self._steps += T
         self._obs_stale = not obs
         return rec
@@ -451,7 +453,7 @@ class VecEnviron(ParamAttrs):
     def bind_step_many(self, actions: torch.Tensor, partner: torch.Tensor, n_groups: torch.Tensor,
                        arrivals: Optional[torch.Tensor] = None, metrics: bool = True, power_w: bool = False,
                        obs: bool = True, policy_action: bool = False,
-                       out: Optional[Dict[str, torch.Tensor]] = None):
+                       out: Optional[Dict[str, torch.Tensor]] = None, fused: bool = True):
         """`step_many` validated and marshalled once: returns a zero-argument launcher that advances the env by
         T steps per call, reading `actions` [T,E,...] (and `arrivals`) in place and writing the per-step records
         into `out`'s tensors ("reward" [T,E,V], "obs" [T,E,V,5], "metrics" [T,E,16]; any subset)."""
@@ -469,7 +471,8 @@ class VecEnviron(ParamAttrs):
         tj = N.RisVecTraj(_dev_ptr(rec.get("reward")), _dev_ptr(rec.get("obs")), _dev_ptr(rec.get("metrics")))
         flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
                  | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0))
-        fn, cs, seed, stream = N.load().risvec_step_fused_multi, C.byref(self._cstate), C.c_uint64(self.seed), self._stream()
+        fn = N.load().risvec_step_fused_multi if fused else N.load().risvec_step_multi
+        cs, seed, stream = C.byref(self._cstate), C.c_uint64(self.seed), self._stream()
         pa, pp, pn, par, ptj = _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng), _dev_ptr(ar), C.byref(tj)
 
         def launch() -> None:

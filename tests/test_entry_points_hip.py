@@ -333,7 +333,8 @@ def test_small_batch_kernel_is_the_pipelined_kernel_bit_for_bit(E, V, M):
 def test_multi_step_launch_equals_single_launches(E, V, M, T, inject):
     """risvec_step_fused_multi == T consecutive risvec_step_fused calls, bit for bit: final state and outputs, and
     every step's trajectory record equals what the env's tensors held after that single step (compile-time shapes
-    take the one-launch kernel; (5,21) and (16,256) go through the documented launch-per-step form)."""
+    take the one-launch kernel; (5,21) and (16,256) take one fused launch for step 0 and the cached-gain multi-step
+    kernel for the rest)."""
     rng = np.random.default_rng(E + M + T)
     _, partner, ng, _ = random_step_inputs(E, V, rng)
     actions = rng.uniform(-0.1, 1.2, (T, E, 2, V)).astype(np.float32)
@@ -357,6 +358,42 @@ def test_multi_step_launch_equals_single_launches(E, V, M, T, inject):
     one.step(actions[0], pt, ngt, None, fused=True, power_w=False)
     many.step(actions[0], pt, ngt, None, fused=True, power_w=False)
     assert torch.equal(many.tensors["data_buf"], one.tensors["data_buf"])
+
+
+@pytest.mark.parametrize("E,V,M,T", [(4096, 8, 36, 6), (301, 8, 40, 5), (130, 5, 21, 4), (257, 16, 256, 5), (77, 4, 16, 3),
+                                     (1000, 13, 20, 3), (9, 8, 64, 1), (40000, 8, 64, 3)])
+@pytest.mark.parametrize("inject", [False, True])
+def test_cached_multi_step_launch_equals_single_launches(E, V, M, T, inject):
+    """risvec_step_multi (`step_many(..., fused=False)`) == T consecutive risvec_step calls on the cached gains, bit for
+    bit, for any shape: final state, outputs and every step's trajectory record -- the reference driver's own cadence
+    (gains every 100 steps, step() every step; marl_train_bcd.py:1304-1611) in one launch."""
+    rng = np.random.default_rng(E + M + T + 1)
+    _, partner, ng, _ = random_step_inputs(E, V, rng)
+    actions = rng.uniform(-0.1, 1.2, (T, E, 2, V)).astype(np.float32)
+    arrivals = rng.poisson(1.0, (T, E, V)).astype(np.int32) if inject else None
+    pt, ngt = partner.astype(np.int32), ng.astype(np.int32)
+    keys = ("gain", "reward", "data_buf", "mec_q", "rate", "data_t", "data_p", "over_power", "obs", "metrics")
+    one, many = _rollout_env(E, V, M), _rollout_env(E, V, M)
+    one.update_channel_gains(); many.update_channel_gains()
+    per_step = []
+    for t in range(T):
+        one.step(actions[t], pt, ngt, None if arrivals is None else arrivals[t], fused=False, power_w=False)
+        per_step.append({k: cpu(one.tensors[k]).copy() for k in ("reward", "obs", "metrics")})
+    rec = many.step_many(actions, pt, ngt, arrivals, fused=False)
+    assert many._steps == one._steps == T
+    for k in keys:
+        assert np.array_equal(cpu(many.tensors[k]), cpu(one.tensors[k])), k
+    for t in range(T):
+        for k in ("reward", "obs", "metrics"):
+            assert np.array_equal(cpu(rec[k][t]), per_step[t][k]), (t, k)
+    # the bound launcher does the same, and the Philox stream / state continue
+    launch = many.bind_step_many(torch.as_tensor(actions).cuda(), torch.as_tensor(pt).cuda(), torch.as_tensor(ngt).cuda(),
+                                 None if arrivals is None else torch.as_tensor(arrivals).cuda(), fused=False)
+    launch()
+    for t in range(T):
+        one.step(actions[t], pt, ngt, None if arrivals is None else arrivals[t], fused=False, power_w=False)
+    for k in keys:
+        assert np.array_equal(cpu(many.tensors[k]), cpu(one.tensors[k])), k
 
 
 def test_multi_step_launch_options_and_errors():
