@@ -540,16 +540,19 @@ __device__ __forceinline__ void multi_step_loop(const Dims& d, const RisVecParam
     // this lane's word(s) of action[t]: [T, E, V, 2] (policy layout) or [T, E, 2, V]
     const float* ap = A.action + (pol ? idx * 2 : (long long)e * 2 * V + v);
     const long long a1_off = pol ? 1 : V;
+    // The last step is peeled: only it writes the env's own tensors, so inside the loop `store_state` is a constant
+    // false -- no branch on it, and the eleven output pointers (spilled: the kernel is at the SGPR limit) are not
+    // read back from their spill lanes once per step.
+    tj.store_state = false;
 #pragma unroll 1
-    for (int t = 0; t < n_steps; ++t) {
-        // next step's action: in flight during this step's arithmetic (the last step re-reads its own)
-        if (t + 1 < n_steps) ap += 2 * ev;
+    for (int t = 0; t + 1 < n_steps; ++t) {
+        // next step's action: in flight during this step's arithmetic
+        ap += 2 * ev;
         float a0n = 0.f, a1n = 0.f;
         if (active) {
             a0n = ap[0];
             a1n = ap[a1_off];
         }
-        tj.store_state = t == n_steps - 1;
         const StepCarry c = step_core<VP, true, true>(d, P, At, e, v, active, g, in, &tj);
         At.counter += 1u;
         At.arrivals += ar_stride;
@@ -561,6 +564,8 @@ __device__ __forceinline__ void multi_step_loop(const Dims& d, const RisVecParam
         in.a0 = a0n;
         in.a1 = a1n;
     }
+    tj.store_state = true;
+    step_core<VP, true, true>(d, P, At, e, v, active, g, in, &tj);
 }
 
 }  // namespace risvec
