@@ -78,6 +78,14 @@ def test_api_rejects_bad_arguments_without_touching_a_gpu():
     assert b"NULL" in lib.risvec_last_error()
     with pytest.raises(ValueError):
         N.check(N.ERR_ARG)
+    # the two T-step entry points validate before they launch: n_steps, flags, NULL inputs
+    for fn in (lib.risvec_step_fused_multi, lib.risvec_step_multi):
+        assert fn(C.byref(s), None, 4, None, None, None, None, 0, 0, 0, None, None) == N.ERR_ARG       # params NULL
+        assert fn(C.byref(s), C.byref(p), 0, None, None, None, None, 0, 0, 0, None, None) == N.ERR_ARG
+        assert b"n_steps" in lib.risvec_last_error()
+        assert fn(C.byref(s), C.byref(p), 4, None, None, None, None, 0, 0, N.STEP_REUSE_IDX, None, None) == N.ERR_ARG
+        assert fn(C.byref(s), C.byref(p), 4, None, None, None, None, 0, 0, 0, None, None) == N.ERR_ARG  # NULL actions
+        assert b"NULL" in lib.risvec_last_error()
 
 
 def test_yaml_key_map_matches_reference_effective_values():
