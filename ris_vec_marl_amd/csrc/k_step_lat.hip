@@ -28,7 +28,19 @@ namespace risvec {
 
 // STAMP: diagnostic build (tools/lat_stamps.py): TJ.reward is a debug buffer that receives, per wavefront, the
 // s_memrealtime (100 MHz) of: entry, all loads issued, cascade reduced (loads returned), step() done, stores drained.
-template <int V, int M, int EPWT, bool MULTI, bool STAMP = false>
+// NT: h_r / theta loads carry the non-temporal hint (streams beyond the 256 MiB Infinity Cache: see launch_step_fused_lat)
+template <bool NT>
+__device__ __forceinline__ float4 lat_ld(const float4* p) {
+    if constexpr (NT) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    } else {
+        return *p;
+    }
+}
+
+template <int V, int M, int EPWT, bool MULTI, bool STAMP = false, bool NT = false>
 __global__ void __launch_bounds__(kBlock)
 k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ) {
     using S = PipeShape<V, M>;
@@ -100,13 +112,13 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
             for (int pc = 0; pc < PC; ++pc) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    u[k].h[pc][it] = hb[row_off + (unsigned)pcl[it] + ((c * PC + pc) * VPP * NP)];
+                    u[k].h[pc][it] = lat_ld<NT>(hb + (row_off + (unsigned)pcl[it] + ((c * PC + pc) * VPP * NP)));
                 }
             }
             if (c == 0) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    u[k].t[it] = tb[pcl[it]];
+                    u[k].t[it] = lat_ld<NT>(tb + pcl[it]);
                 }
             }
         }
@@ -201,6 +213,25 @@ static hipError_t launch_lat_vm(const RisVecState& s, const RisVecParams& p, con
     }
 }
 
+// 4 envs per wavefront, single step, non-temporal loads
+template <int V, int M>
+static hipError_t launch_lat_nt(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
+    const long long waves = ((long long)s.n_envs + 3) / 4;
+    const unsigned grid = (unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave));
+    const RisVecTraj none{nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL((k_step_fused_lat<V, M, 4, false, false, true>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, 1, none);
+    return hipGetLastError();
+}
+
+static hipError_t dispatch_lat_nt(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
+    const int V = s.n_veh, M = s.n_ris;
+    if (V == 8 && M == 64) return launch_lat_nt<8, 64>(s, p, a, st);
+    if (V == 8 && M == 36) return launch_lat_nt<8, 36>(s, p, a, st);
+    if (V == 8 && M == 40) return launch_lat_nt<8, 40>(s, p, a, st);
+    if (V == 4 && M == 16) return launch_lat_nt<4, 16>(s, p, a, st);
+    return hipErrorNotSupported;
+}
+
 template <bool MULTI>
 static hipError_t dispatch_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
                                const RisVecTraj& tj, int epwt, hipStream_t st) {
@@ -226,6 +257,23 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
         const char* e = std::getenv("RISVEC_LAT_MAX_ENVS");
         return e ? std::atoll(e) : 24576LL;
     }();
+    // Beyond the Infinity Cache (h_r + theta of one step > RISVEC_PIPE_NT_MB = 270 MB, where the pipeline switches to
+    // non-temporal loads too) this kernel comes back with the non-temporal hint: many short hardware-dispatched
+    // wavefronts with every request up front are what the best pure reader looks like, and they beat the pipeline's
+    // 2 048 long-lived wavefronts by 1-4 % there (tools/gpu_latnt.sh, profiles/r02t_lat_nt_experiment.txt, us per step
+    // pipeline / this: 65 536 envs 59.3 / 58.5, 131 072 115.8 / 111.9, 262 144 223.6 / 217.1; with the default cache
+    // policy it loses 7-12 % at those sizes, and inside the cache (24 576 < envs <= ~57 000) the pipeline stays).
+    // RISVEC_LAT_NT = 0 never / 1 always (tests) / 2 by size.
+    static const int nt_mode = [] { const char* e = std::getenv("RISVEC_LAT_NT"); return e ? std::atoi(e) : 2; }();
+    static const long long nt_from = [] {
+        const char* e = std::getenv("RISVEC_PIPE_NT_MB");
+        return (e ? std::atoll(e) : 270LL) << 20;
+    }();
+    const long long stream_bytes = (long long)s.n_envs * (8LL * s.n_veh * s.n_ris + 8LL * s.n_ris);
+    if (limit > 0 && epw >= 4 && (nt_mode == 1 || (nt_mode == 2 && stream_bytes > nt_from))) {
+        const hipError_t err = dispatch_lat_nt(s, p, a, st);
+        if (err != hipErrorNotSupported) return err;
+    }
     if ((long long)s.n_envs > limit) return hipErrorNotSupported;
     const int epwt = lat_epwt(s.n_envs, epw);
     if (epwt <= 0) return hipErrorNotSupported;

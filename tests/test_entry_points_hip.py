@@ -512,3 +512,13 @@ def test_non_temporal_variants_are_bit_identical(E, V, M):
         assert set(outs[0].files) == set(outs[1].files) and len(outs[0].files) == 11
         for k in outs[0].files:
             assert np.array_equal(outs[0][k], outs[1][k]), k
+        # the latency-shaped kernel's non-temporal form (what risvec_step_fused takes beyond ~270 MB per step), forced
+        # at this size with RISVEC_LAT_NT=1: same bits again (shapes without that kernel stay in the pipeline)
+        e = dict(os.environ, RISVEC_LAT_NT="1", RISVEC_PIPE_NT="0", RISVEC_COLSUM_NT="0")
+        dst = os.path.join(tmp, "lat_nt.npz")
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), dst], env=e, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lat = np.load(dst)
+        for k in outs[0].files:
+            assert np.array_equal(outs[0][k], lat[k]), k
