@@ -457,8 +457,10 @@ class Case:
             return "k_step_multi (T-step launch on cached gains)"
         if self.mode == "fused" and getattr(self.opts, "multi", 0) > 1:
             return "k_step_fused<..> once + k_step_multi (T-step launch, shape without a compile-time fused kernel)"
-        if self.mode in ("fused", "bcd") and lat and self.E * (8 * self.V * self.M + 8 * self.M) > (270 << 20):
-            k = "k_step_fused_lat<%d,%d,4,NT> (4 envs per wavefront, non-temporal loads: stream beyond the Infinity Cache)" % (self.V, self.M)
+        if (self.mode in ("fused", "bcd") and (lat or (self.V, self.M) == (16, 256))
+                and self.E * (8 * self.V * self.M + 8 * self.M) > (270 << 20)):
+            k = ("k_step_fused_lat<%d,%d,%d,NT> (%d env(s) per wavefront, every request up front, non-temporal loads: stream "
+                 "beyond the Infinity Cache)" % (self.V, self.M, 1 if self.V == 16 else 4, 1 if self.V == 16 else 4))
             return k if self.mode == "fused" else "k_bcd_sweep + " + k
         if self.mode == "fused" and lat and self.E <= int(os.environ.get("RISVEC_LAT_MAX_ENVS", "24576")):
             return "k_step_fused_lat<%d,%d,..> (latency-shaped: up to 24 576 envs)" % (self.V, self.M)

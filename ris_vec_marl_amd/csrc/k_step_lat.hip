@@ -122,6 +122,10 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
                 }
             }
         }
+        // 16 x 256 (one env = 34 loads per lane): left alone the compiler starts reducing before the last request is
+        // out, to stay at 123 registers; with every request up front (168 registers, 3 wavefronts per SIMD) BASELINE
+        // configs[4] is 0.8 % faster.  At 8 x 64 the same barrier measured neutral, at the configs[3] shard slower.
+        if constexpr (NT && V == 16) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < UB; ++k) {
             const int ui = b0 + k;
@@ -213,13 +217,13 @@ static hipError_t launch_lat_vm(const RisVecState& s, const RisVecParams& p, con
     }
 }
 
-// 4 envs per wavefront, single step, non-temporal loads
-template <int V, int M>
+// EPWT envs per wavefront (4; 1 at 16 x 256, where one env is already 34 KB in flight), single step, non-temporal loads
+template <int V, int M, int EPWT = 4>
 static hipError_t launch_lat_nt(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
-    const long long waves = ((long long)s.n_envs + 3) / 4;
+    const long long waves = ((long long)s.n_envs + EPWT - 1) / EPWT;
     const unsigned grid = (unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave));
     const RisVecTraj none{nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL((k_step_fused_lat<V, M, 4, false, false, true>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, 1, none);
+    hipLaunchKernelGGL((k_step_fused_lat<V, M, EPWT, false, false, true>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, 1, none);
     return hipGetLastError();
 }
 
@@ -229,6 +233,7 @@ static hipError_t dispatch_lat_nt(const RisVecState& s, const RisVecParams& p, c
     if (V == 8 && M == 36) return launch_lat_nt<8, 36>(s, p, a, st);
     if (V == 8 && M == 40) return launch_lat_nt<8, 40>(s, p, a, st);
     if (V == 4 && M == 16) return launch_lat_nt<4, 16>(s, p, a, st);
+    if (V == 16 && M == 256) return launch_lat_nt<16, 256, 1>(s, p, a, st);
     return hipErrorNotSupported;
 }
 
@@ -263,6 +268,8 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
     // 2 048 long-lived wavefronts by 1-4 % there (tools/gpu_latnt.sh, profiles/r02t_lat_nt_experiment.txt, us per step
     // pipeline / this: 65 536 envs 59.3 / 58.5, 131 072 115.8 / 111.9, 262 144 223.6 / 217.1; with the default cache
     // policy it loses 7-12 % at those sizes, and inside the cache (24 576 < envs <= ~57 000) the pipeline stays).
+    // BASELINE configs[4] (32 768 x 16 x 256, 1.1 GB per step, one env per wavefront): 251.5 -> 233 us per step with
+    // the BCD sweep, i.e. the fused kernel 198 -> 180 us.
     // RISVEC_LAT_NT = 0 never / 1 always (tests) / 2 by size.
     static const int nt_mode = [] { const char* e = std::getenv("RISVEC_LAT_NT"); return e ? std::atoi(e) : 2; }();
     static const long long nt_from = [] {
