@@ -450,8 +450,9 @@ class Case:
         if self.opts.steer and self.fused:
             return "k_step_steer"
         pipe = (self.V, self.M) in ((8, 64), (8, 36), (8, 40), (4, 16), (16, 64), (16, 256))
-        lat = (self.V, self.M) in ((8, 64), (8, 36), (8, 40), (4, 16))          # csrc/k_step_lat.hip
-        if self.mode == "fused" and lat and getattr(self.opts, "multi", 0) > 1:
+        lat = ((self.V, self.M) in ((8, 64), (8, 36), (8, 40), (4, 16), (16, 256))          # csrc/k_step_lat.hip
+               or ((self.V, self.M) == (16, 64) and self.E <= 8192))
+        if self.mode == "fused" and lat and self.V != 16 and getattr(self.opts, "multi", 0) > 1:
             return "k_step_fused_lat<%d,%d,..,MULTI> (T-step launch)" % (self.V, self.M)
         if self.mode == "cached" and getattr(self.opts, "multi", 0) > 1:
             return "k_step_multi (T-step launch on cached gains)"
@@ -462,8 +463,9 @@ class Case:
             k = ("k_step_fused_lat<%d,%d,%d,NT> (%d env(s) per wavefront, every request up front, non-temporal loads: stream "
                  "beyond the Infinity Cache)" % (self.V, self.M, 1 if self.V == 16 else 4, 1 if self.V == 16 else 4))
             return k if self.mode == "fused" else "k_bcd_sweep + " + k
-        if self.mode == "fused" and lat and self.E <= int(os.environ.get("RISVEC_LAT_MAX_ENVS", "24576")):
-            return "k_step_fused_lat<%d,%d,..> (latency-shaped: up to 24 576 envs)" % (self.V, self.M)
+        if self.mode in ("fused", "bcd") and lat and self.E <= int(os.environ.get("RISVEC_LAT_MAX_ENVS", "24576")):
+            k = "k_step_fused_lat<%d,%d,..> (latency-shaped: small and medium batches)" % (self.V, self.M)
+            return k if self.mode == "fused" else "k_bcd_sweep + " + k
         k = "k_step_fused_pipe<%d,%d,..>" % (self.V, self.M) if pipe else "k_step_fused<..>"
         return {"fused": k.replace("..>", "..,MarlCore>") if pipe else k, "cached": "k_step",
                 "bcd": "k_bcd_sweep + " + k, "sarl": "k_set_phase + " + k.replace("..>", "..,SarlCore>")}[self.mode]

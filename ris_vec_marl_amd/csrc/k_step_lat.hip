@@ -241,6 +241,17 @@ template <bool MULTI>
 static hipError_t dispatch_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
                                const RisVecTraj& tj, int epwt, hipStream_t st) {
     const int V = s.n_veh, M = s.n_ris;
+    if constexpr (!MULTI) {
+        // 16 vehicles, single step (tools/gpu_v16.sh, us per step pipeline / this): 16 x 256 with one env per wavefront
+        // 2 048 envs 14.6 / 13.5, 4 096 25.3 / 23.4, 7 168 40.1 / 38.7 (and the non-temporal form beyond 270 MB per step:
+        // launch_step_fused_lat); 16 x 64: 4 096 envs 8.0 / 7.0, 8 192 14.5 / 14.5, from 16 384 the pipeline wins.
+        if (V == 16 && M == 256) return launch_lat_shape<16, 256, 1, false>(s, p, a, 1, tj, st);
+        if (V == 16 && M == 64 && s.n_envs <= 8192) {
+            if (epwt >= 4) return launch_lat_shape<16, 64, 4, false>(s, p, a, 1, tj, st);
+            if (epwt == 2) return launch_lat_shape<16, 64, 2, false>(s, p, a, 1, tj, st);
+            return launch_lat_shape<16, 64, 1, false>(s, p, a, 1, tj, st);
+        }
+    }
     if (V == 8 && M == 64) return launch_lat_vm<8, 64, MULTI>(s, p, a, n_steps, tj, epwt, st);
     if (V == 8 && M == 36) return launch_lat_vm<8, 36, MULTI>(s, p, a, n_steps, tj, epwt, st);
     if (V == 8 && M == 40) return launch_lat_vm<8, 40, MULTI>(s, p, a, n_steps, tj, epwt, st);

@@ -292,7 +292,8 @@ def _rollout_env(E, V, M, seed=9):
     return env
 
 
-@pytest.mark.parametrize("E,V,M", [(4096, 8, 36), (8192, 8, 64), (1000, 8, 40), (515, 4, 16), (1, 8, 64), (3, 8, 36)])
+@pytest.mark.parametrize("E,V,M", [(4096, 8, 36), (8192, 8, 64), (1000, 8, 40), (515, 4, 16), (1, 8, 64), (3, 8, 36),
+                                   (301, 16, 256), (2050, 16, 64), (5, 16, 64)])
 def test_small_batch_kernel_is_the_pipelined_kernel_bit_for_bit(E, V, M):
     """Below ~12k envs `risvec_step_fused` takes the latency-shaped single-group kernel (k_step_lat.hip); same
     arithmetic in the same order as the software pipeline, so every output must be identical.  RISVEC_LAT_MAX_ENVS=0
