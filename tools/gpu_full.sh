@@ -29,6 +29,8 @@ b c3_multi32 --multi 32 --steps 3200
 b big --config big --steps 300 --warmup 30
 b c5 --config c5 --steps 300 --warmup 30
 b cached --mode cached
+b cached_multi32 --mode cached --multi 32 --steps 3200
+b c5_cached_multi32 --config c5 --mode cached --multi 32 --steps 3200
 b noma --noma
 b cached_noma --mode cached --noma
 b replay --replay

@@ -12,6 +12,9 @@ for r in csv.DictReader(open(stats)):
     key = next((k for k in sorted(B, key=len, reverse=True) if k in name), None)
     if "k_step_fused_pipe" in name:      # one pipeline, three cores: price each against its own bytes
         key = "k_sarl_step" if "SarlCore" in name else "k_gain" if "GainCore" in name else "k_step_fused"
+    if "k_step_fused_lat<" in name:      # single-step instantiations are priced as the fused step, the T-step ones by their own bytes
+        args = name.split("k_step_fused_lat<", 1)[1].split(">", 1)[0].split(",")
+        key = "k_step_fused_lat" if len(args) > 3 and args[3].strip() == "true" else "k_step_fused"
     if key is None or "at::native" in name:
         continue
     avg_us = float(r["AverageNs"]) / 1e3

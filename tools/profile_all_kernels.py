@@ -49,6 +49,7 @@ for _ in range(reps):
     env.step(action, partner, ng, None, fused=True, power_w=False, steer=True)      # k_step_steer
     if (V, M) in ((8, 64), (8, 36), (8, 40), (4, 16)):
         env.step_many(actions_T, partner, ng, None)                   # k_step_fused_lat<.., MULTI>: T = 16 steps in one launch
+    env.step_many(actions_T, partner, ng, None, fused=False)          # k_step_multi: T = 16 steps on the cached gains, any shape
     env.sarl_step(action, phase)
     env.channel_model = "3gpp_umi"
     env.update_channel_gains()
@@ -77,7 +78,7 @@ B = dict(
     k_bcd_sweep=E * (2 * 16 * M + 2 * 8 * M + 8 * M), k_bcd_sweep8_idx=E * (16 * M + 2 * M + 8 * M + 32),
     k_colsum_slab=E * (8 * V * M + 16 * M),
     k_step_fused_lat=E * (8 * V * M + 8 * M + 16 * (8 * V + 24 * V + 64) + 40 * V + 8), k_gain=E * (8 * V * M + 8 * M + 8 * V),
-    k_data_rate=E * 16 * V + 4 * E, k_step=E * (60 * V + 68), k_step_fused=E * (8 * V * M + 8 * M + 64 * V + 68),
+    k_data_rate=E * 16 * V + 4 * E, k_step=E * (60 * V + 68), k_step_multi=E * 16 * (8 * V + 24 * V + 64) + E * (60 * V + 68), k_step_fused=E * (8 * V * M + 8 * M + 64 * V + 68),
     k_step_steer=E * (16 * V + 8 * M + 64 * V + 68),
     k_sarl_step=E * (8 * V * M + 8 * M + 48 * V + 4), k_gain_3gpp=E * V * 20,
     # f2 / f3 (float words read + written; the NOMA kernels are latency-bound, bytes listed for completeness)
