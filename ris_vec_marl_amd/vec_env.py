@@ -127,14 +127,20 @@ class VecEnviron(ParamAttrs):
         t["h_r"] = z(E, V, M, 2)        # all-zero until compute_parms(), like Environment.py:162
         t["theta"] = z(E, M, 2)         # all-zero start, Environment.py:171
         t["b"] = torch.from_numpy(np.stack([self.phase_R.real, self.phase_R.imag], -1).astype(np.float32)).to(dev)
-        t["gain"] = z(E, V)
-        t["data_buf"] = z(E, V)
-        t["mec_q"] = z(E)
-        for k in ("rate", "data_t", "data_p", "reward", "over_power", "over_data"):
-            t[k] = z(E, V)
-        t["obs"] = z(E, V, 5)
-        t["metrics"] = z(E, N.METRICS)
-        t["power_w"] = z(E, 2, V)
+        # step()'s per-env float32 state and outputs are views into ONE allocation (each view 256-byte aligned): the
+        # kernels do not care, and a host that wants them all after a step -- the E = 1 facade, which returns the
+        # reference's 7-tuple and 13 last_* scalars as NumPy values -- reads them back with one copy instead of nine
+        slab_shapes = [("reward", (E, V)), ("over_power", (E, V)), ("data_buf", (E, V)), ("data_t", (E, V)),
+                       ("data_p", (E, V)), ("over_data", (E, V)), ("rate", (E, V)), ("gain", (E, V)), ("mec_q", (E,)),
+                       ("metrics", (E, N.METRICS)), ("power_w", (E, 2, V)), ("obs", (E, V, 5))]
+        offs, n = {}, 0
+        for k, shp in slab_shapes:
+            offs[k] = n
+            n += (int(np.prod(shp)) + 63) // 64 * 64
+        slab = z(n)
+        for k, shp in slab_shapes:
+            t[k] = slab[offs[k]:offs[k] + int(np.prod(shp))].view(*shp)
+        self._out_slab, self._out_offsets = slab, {k: (offs[k], shp) for k, shp in slab_shapes}
         # BCD column sums (sum_v h_r) * b in f64, lane-major slabs of 64 envs: [ceil(E/64), M, 64, 2]
         t["c_col"] = z((E + 63) // 64, M, 64, 2, dt=torch.float64)
         t["s_sum"] = z(E, 2, dt=torch.float64)         # sum_m theta_m c_m left by the last sweep
