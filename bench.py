@@ -459,7 +459,7 @@ class Case:
         if self.mode == "fused" and getattr(self.opts, "multi", 0) > 1:
             return "k_step_fused<..> once + k_step_multi (T-step launch, shape without a compile-time fused kernel)"
         if (self.mode in ("fused", "bcd") and (lat or (self.V, self.M) == (16, 256))
-                and self.E * (8 * self.V * self.M + 8 * self.M) > (270 << 20)):
+                and self.E * (8 * self.V * self.M + 8 * self.M) > (330 << 20)):
             k = ("k_step_fused_lat<%d,%d,%d,NT> (%d env(s) per wavefront, every request up front, non-temporal loads: stream "
                  "beyond the Infinity Cache)" % (self.V, self.M, 1 if self.V == 16 else 4, 1 if self.V == 16 else 4))
             return k if self.mode == "fused" else "k_bcd_sweep + " + k

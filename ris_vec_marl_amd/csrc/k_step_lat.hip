@@ -243,7 +243,7 @@ static hipError_t dispatch_lat(const RisVecState& s, const RisVecParams& p, cons
     const int V = s.n_veh, M = s.n_ris;
     if constexpr (!MULTI) {
         // 16 vehicles, single step (tools/gpu_v16.sh, us per step pipeline / this): 16 x 256 with one env per wavefront
-        // 2 048 envs 14.6 / 13.5, 4 096 25.3 / 23.4, 7 168 40.1 / 38.7 (and the non-temporal form beyond 270 MB per step:
+        // 2 048 envs 14.6 / 13.5, 4 096 25.3 / 23.4, 7 168 40.1 / 38.7 (and the non-temporal form beyond 330 MB per step:
         // launch_step_fused_lat); 16 x 64: 4 096 envs 8.0 / 7.0, 8 192 14.5 / 14.5, from 16 384 the pipeline wins.
         if (V == 16 && M == 256) return launch_lat_shape<16, 256, 1, false>(s, p, a, 1, tj, st);
         if (V == 16 && M == 64 && s.n_envs <= 8192) {
@@ -273,8 +273,8 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
         const char* e = std::getenv("RISVEC_LAT_MAX_ENVS");
         return e ? std::atoll(e) : 24576LL;
     }();
-    // Beyond the Infinity Cache (h_r + theta of one step > RISVEC_PIPE_NT_MB = 270 MB, where the pipeline switches to
-    // non-temporal loads too) this kernel comes back with the non-temporal hint: many short hardware-dispatched
+    // Beyond the Infinity Cache (h_r + theta of one step > RISVEC_LAT_NT_MB = 330 MB; the pipeline switches to
+    // non-temporal loads from 270 MB) this kernel comes back with the non-temporal hint: many short hardware-dispatched
     // wavefronts with every request up front are what the best pure reader looks like, and they beat the pipeline's
     // 2 048 long-lived wavefronts by 1-4 % there (tools/gpu_latnt.sh, profiles/r02t_lat_nt_experiment.txt, us per step
     // pipeline / this: 65 536 envs 59.3 / 58.5, 131 072 115.8 / 111.9, 262 144 223.6 / 217.1; with the default cache
@@ -283,9 +283,11 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
     // the BCD sweep, i.e. the fused kernel 198 -> 180 us.
     // RISVEC_LAT_NT = 0 never / 1 always (tests) / 2 by size.
     static const int nt_mode = [] { const char* e = std::getenv("RISVEC_LAT_NT"); return e ? std::atoi(e) : 2; }();
+    // (its own threshold: tools/gpu_nt_threshold.sh at 16 x 256, us per step default / non-temporal: 221 MB 33.4 / 35.8,
+    // 294 MB 43.9 / 47.4, 368 MB 66.2 / 59.9, 441 MB 78.5 / 71.0, 588 MB 107.4 / 96.6 -- the crossover is near 330 MB)
     static const long long nt_from = [] {
-        const char* e = std::getenv("RISVEC_PIPE_NT_MB");
-        return (e ? std::atoll(e) : 270LL) << 20;
+        const char* e = std::getenv("RISVEC_LAT_NT_MB");
+        return (e ? std::atoll(e) : 330LL) << 20;
     }();
     const long long stream_bytes = (long long)s.n_envs * (8LL * s.n_veh * s.n_ris + 8LL * s.n_ris);
     if (limit > 0 && epw >= 4 && (nt_mode == 1 || (nt_mode == 2 && stream_bytes > nt_from))) {
