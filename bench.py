@@ -463,7 +463,8 @@ class Case:
             k = ("k_step_fused_lat<%d,%d,%d,NT> (%d env(s) per wavefront, every request up front, non-temporal loads: stream "
                  "beyond the Infinity Cache)" % (self.V, self.M, 1 if self.V == 16 else 4, 1 if self.V == 16 else 4))
             return k if self.mode == "fused" else "k_bcd_sweep + " + k
-        if self.mode in ("fused", "bcd") and lat and self.E <= int(os.environ.get("RISVEC_LAT_MAX_ENVS", "24576")):
+        if self.mode in ("fused", "bcd") and lat and (self.E <= int(os.environ.get("RISVEC_LAT_MAX_ENVS", "24576"))
+                                                      or (self.V == 8 and self.M in (36, 40))):
             k = "k_step_fused_lat<%d,%d,..> (latency-shaped: small and medium batches)" % (self.V, self.M)
             return k if self.mode == "fused" else "k_bcd_sweep + " + k
         k = "k_step_fused_pipe<%d,%d,..>" % (self.V, self.M) if pipe else "k_step_fused<..>"

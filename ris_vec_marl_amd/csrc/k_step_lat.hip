@@ -294,7 +294,11 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
         const hipError_t err = dispatch_lat_nt(s, p, a, st);
         if (err != hipErrorNotSupported) return err;
     }
-    if ((long long)s.n_envs > limit) return hipErrorNotSupported;
+    // M = 36 / 40 (18 / 20 float4 per row on 32 lanes): this kernel at EVERY size -- the pipeline's unit loader wastes the
+    // same lanes and gains nothing back (tools/gpu_crossover.sh, profiles/r02u_lat_vs_pipe_ragged.txt, us per step this
+    // kernel / pipeline at M = 40: 32 768 envs 19.3 / 19.6, 65 536 34.2 / 34.7, 98 304 62.5 / 65.7; M = 36: 65 536 31.6 / 32.7)
+    const bool ragged = s.n_veh == 8 && (s.n_ris == 36 || s.n_ris == 40) && limit > 0;
+    if ((long long)s.n_envs > limit && !ragged) return hipErrorNotSupported;
     const int epwt = lat_epwt(s.n_envs, epw);
     if (epwt <= 0) return hipErrorNotSupported;
     const RisVecTraj none{nullptr, nullptr, nullptr};
