@@ -293,7 +293,10 @@ def _rollout_env(E, V, M, seed=9):
 
 
 @pytest.mark.parametrize("E,V,M", [(4096, 8, 36), (8192, 8, 64), (1000, 8, 40), (515, 4, 16), (1, 8, 64), (3, 8, 36),
-                                   (301, 16, 256), (2050, 16, 64), (5, 16, 64)])
+                                   (301, 16, 256), (2050, 16, 64), (5, 16, 64),
+                                   # every envs-per-wavefront instantiation of every shape (1 / 2 / 4 by batch size)
+                                   (8192, 16, 64), (4100, 16, 64), (9000, 8, 40), (4500, 8, 40), (20000, 4, 16), (5000, 4, 16),
+                                   (2100, 8, 64), (5000, 8, 64), (9000, 8, 36)])
 def test_small_batch_kernel_is_the_pipelined_kernel_bit_for_bit(E, V, M):
     """Below ~12k envs `risvec_step_fused` takes the latency-shaped single-group kernel (k_step_lat.hip); same
     arithmetic in the same order as the software pipeline, so every output must be identical.  RISVEC_LAT_MAX_ENVS=0
