@@ -332,7 +332,8 @@ def test_small_batch_kernel_is_the_pipelined_kernel_bit_for_bit(E, V, M):
 
 
 @pytest.mark.parametrize("E,V,M,T", [(4096, 8, 36, 7), (8192, 8, 64, 4), (301, 8, 40, 5), (77, 4, 16, 3), (40000, 8, 64, 3),
-                                     (130, 5, 21, 4), (64, 16, 256, 2), (9, 8, 64, 1)])
+                                     (130, 5, 21, 4), (64, 16, 256, 2), (9, 8, 64, 1), (3000, 8, 36, 3), (2500, 8, 40, 2),
+                                     (9000, 4, 16, 3)])
 @pytest.mark.parametrize("inject", [False, True])
 def test_multi_step_launch_equals_single_launches(E, V, M, T, inject):
     """risvec_step_fused_multi == T consecutive risvec_step_fused calls, bit for bit: final state and outputs, and
