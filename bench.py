@@ -359,7 +359,7 @@ class Case:
             from ris_vec_marl_amd.sarl import SarlParams
             phase = torch.from_numpy(rng.uniform(0, 2 * np.pi, (E, M)).astype(np.float32)).to(device)
             sp = SarlParams()
-            launch = lambda: env.sarl_step(action, phase, None, sp, obs=full)       # noqa: E731
+            launch = env.bind_sarl_step(action, phase, None, sp, obs=full)
         elif getattr(opts, "multi", 0) > 1:
             if mode not in ("fused", "cached") or opts.noma or opts.meter or opts.steer:
                 raise SystemExit("--multi T is the T-step launch of the fused gains+step path, or with --mode cached of the "

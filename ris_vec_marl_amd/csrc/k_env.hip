@@ -320,12 +320,38 @@ k_gain_3gpp(Dims d, RisVecParams P, int model, const double* __restrict__ pos,
 // ---------------------------------------------------------------------------
 // phase setters
 // ---------------------------------------------------------------------------
+// exp(j x) in float64 for |x| <= 1e5: Cody-Waite reduction by pi/2 (two-term split, exact product for |k| < 2^17) and the
+// fdlibm kernel polynomials on [-pi/4, pi/4] -- error < 1e-15, i.e. the float32 image is the correctly rounded one except
+// within 1e-8 ulp of a rounding boundary.  ~30 float64 instructions against the ~150 of the general sincos(), whose
+// range reduction for huge arguments and special cases made k_set_phase VALU-bound (9 us for 25 MB at E = 32 768, M = 64:
+// the SARL step's theta = exp(j action_phase), every step).
+__device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
+    const double kd = rint(x * 0.63661977236758138);                        // round(x * 2/pi)
+    double r = fma(-kd, 1.5707963267341256, x);                              // pi/2, high 33 bits
+    r = fma(-kd, 6.0771005065061922e-11, r);                                 // pi/2, next 53 bits
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                  2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                  -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                 -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double sr = fma(r * z, ps, r);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)kd & 3;
+    const double a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;               // sin, cos before the signs
+    s = (q & 2) ? -a : a;
+    c = (q == 1 || q == 2) ? -b : b;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_set_phase(long long n, const float* __restrict__ angle, float* __restrict__ theta) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    const double x = (double)angle[i];
     double s, c;
-    sincos((double)angle[i], &s, &c);                                       // ENV:239
+    if (fabs(x) <= 1.0e5) sincos_small(x, s, c);
+    else sincos(x, &s, &c);                                                  // ENV:239
     *reinterpret_cast<float2*>(theta + 2 * i) = make_float2((float)c, (float)s);
 }
 

@@ -515,6 +515,33 @@ class VecEnviron(ParamAttrs):
         t = self._t
         return (t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"], t["over_data"])
 
+    def bind_sarl_step(self, action_power: torch.Tensor, action_phase: Optional[torch.Tensor] = None,
+                       arrivals: Optional[torch.Tensor] = None, sarl_params=None, obs: bool = True):
+        """`sarl_step` validated and marshalled once: returns a zero-argument launcher that reads the SAME device
+        tensors on every call (update them in place between calls).  The parameters are those of `sarl_params` at
+        bind time."""
+        from .sarl import SarlParams
+        self._ensure_device()
+        E, V, M = self.n_envs, self.n_veh, self.M
+        a = self._bound(action_power, torch.float32, (E, 2, V), "action_power")
+        ph = self._bound(action_phase, torch.float32, (E, M), "action_phase")
+        ar = self._bound(arrivals, torch.int32, (E, V), "arrivals")
+        sp = (sarl_params or SarlParams()).to_c()
+        fn, cs, psp, seed, stream = N.load().risvec_sarl_step, C.byref(self._cstate), C.byref(sp), C.c_uint64(self.seed), self._stream()
+        pa, pph, par, flags = _dev_ptr(a), _dev_ptr(ph), _dev_ptr(ar), N.STEP_OBS if obs else 0
+
+        def launch() -> None:
+            rc = fn(cs, psp, pa, pph, par, seed, self._steps, flags, stream)
+            if rc:
+                N.check(rc)
+            if ph is not None:
+                self._theta_changed()
+            self._steps += 1
+            self._obs_stale = False
+
+        launch.inputs = (a, ph, ar, sp)
+        return launch
+
     def bind_step(self, action_power, partner, n_groups, arrivals=None, fused: bool = False, bcd: bool = False,
                   metrics: bool = True, power_w: bool = True, obs: bool = True, policy_action: bool = False,
                   steer: bool = False):

@@ -611,6 +611,19 @@ def test_random_phase_and_set_phase():
     a = np.random.default_rng(0).uniform(0, 2 * np.pi, (E, M)).astype(np.float32)
     env.get_next_phase(a)
     np.testing.assert_allclose(c128(env.tensors["theta"]), np.exp(1j * a.astype(np.float64)), atol=1e-7)
+    # the kernel's own float64 sincos (Cody-Waite by pi/2 + the fdlibm kernels for |x| <= 1e5, the library beyond): its
+    # float32 image is the correctly rounded float64 value -- bit for bit against NumPy's, over the angles an agent can
+    # produce, negative and large ones, and the huge-argument fallback
+    rng = np.random.default_rng(1)
+    for lo, hi in ((-2 * np.pi, 2 * np.pi), (-300.0, 300.0), (-9.9e4, 9.9e4), (1.1e5, 3.0e7)):
+        a = rng.uniform(lo, hi, (E, M)).astype(np.float32)
+        a.flat[:4] = np.array([0.0, np.pi / 2, -np.pi, lo], dtype=np.float32)
+        env.get_next_phase(a)
+        ref = np.exp(1j * a.astype(np.float64))
+        got = cpu(env.tensors["theta"])
+        want = np.stack([ref.real, ref.imag], -1).astype(np.float32)
+        assert np.abs(got - want).max() <= 6e-8, (lo, hi)
+        assert np.mean(got != want) < 1e-4, (lo, hi, np.mean(got != want))
 
 
 # ---------------------------------------------------------------------------- protocol (a13-a15)
@@ -945,6 +958,20 @@ def test_sarl_facade_and_philox():
     ob = sarl_observe(venv, ph)
     ref = orc.sarl_obs(cpu(ph).astype(np.float64), cpu(o6[1]), cpu(o6[2]), cpu(o6[3]), cpu(o6[5]), cpu(venv.tensors["rate"]))
     np.testing.assert_allclose(cpu(ob), ref, rtol=2e-6, atol=1e-8)
+    # the pre-bound launcher is the same call: two envs in lock step, bit for bit
+    a_env, b_env = make_vec(300, V, M, seed=3), make_vec(300, V, M, seed=3)
+    for e in (a_env, b_env):
+        e.make_new_game(); e.compute_parms()
+    pw3 = torch.from_numpy(rng.uniform(0, 1, (300, 2, V)).astype(np.float32)).cuda()
+    ph3 = torch.from_numpy(rng.uniform(0, 2 * np.pi, (300, M)).astype(np.float32)).cuda()
+    launch = b_env.bind_sarl_step(pw3, ph3)
+    for _ in range(3):
+        a_env.sarl_step(pw3, ph3)
+        launch()
+    for k in ("reward", "data_buf", "data_t", "data_p", "over_power", "over_data", "theta", "gain", "metrics"):
+        assert torch.equal(a_env.tensors[k], b_env.tensors[k]), k
+    with pytest.raises(ValueError):
+        b_env.bind_sarl_step(cpu(pw3), ph3)                   # a host array is refused, not copied
 
 
 # ---------------------------------------------------------------------------- edge shapes
