@@ -89,14 +89,46 @@ class SarlEnviron(Environ):
                 return
         super().__setattr__(name, value)
 
+    def _sarl_launch(self, a: np.ndarray, ph: np.ndarray, arrivals) -> None:
+        """One env, one step: power | phase | arrivals go to the device in ONE copy of pinned 32-bit words and the launch
+        is pre-bound (re-bound when a parameter of `self.sarl` changed), as in `Environ._step_launch`."""
+        import torch
+        V, M, vec = self.n_veh, self.M, self._vec
+        key = tuple(sorted(vars(self.sarl).items()))
+        st = self.__dict__.get("_sarl_stage")
+        if st is None or st["key"] != key:
+            vec._ensure_device()
+            up4 = lambda n: (n + 3) // 4 * 4                   # noqa: E731  (16-byte aligned sections)
+            o_ph = up4(2 * V)
+            o_ar = o_ph + up4(M)
+            host = torch.zeros(o_ar + up4(V), dtype=torch.int32).pin_memory()
+            dev = torch.zeros(o_ar + up4(V), dtype=torch.int32, device=vec.device)
+            hn = host.numpy()
+            d_a = dev[:2 * V].view(torch.float32).view(1, 2, V)
+            d_ph = dev[o_ph:o_ph + M].view(torch.float32).view(1, M)
+            d_ar = dev[o_ar:o_ar + V].view(1, V)
+            st = dict(key=key, host=host, dev=dev,
+                      a=hn[:2 * V].view(np.float32), ph=hn[o_ph:o_ph + M].view(np.float32), ar=hn[o_ar:o_ar + V],
+                      plain=vec.bind_sarl_step(d_a, d_ph, None, sarl_params=self.sarl),
+                      injected=vec.bind_sarl_step(d_a, d_ph, d_ar, sarl_params=self.sarl))
+            object.__setattr__(self, "_sarl_stage", st)
+        st["a"][:] = a.reshape(-1)
+        st["ph"][:] = ph
+        if arrivals is not None:
+            arr = np.asarray(arrivals)
+            if arr.shape != (V,):
+                raise ValueError("arrivals must have shape [n_veh]")
+            st["ar"][:] = arr
+        st["dev"].copy_(st["host"], non_blocking=True)
+        st["injected" if arrivals is not None else "plain"]()
+
     def step(self, action_power, action_phase, arrivals=None):   # noqa: D102  (signature of SENV:321)
         a = np.asarray(action_power, dtype=np.float64)
         ph = np.asarray(action_phase, dtype=np.float64)
         if a.shape != (2, self.n_veh) or ph.shape != (self.M,):
             raise ValueError("step(action_power [2,n_veh], action_phase [M])")
         self.elements_phase_shift_real = action_phase
-        arr = None if arrivals is None else np.asarray(arrivals)[None]
-        self._vec.sarl_step(a[None], ph[None], arr, sarl_params=self.sarl)
+        self._sarl_launch(a, ph, arrivals)
         self._dirty()
         self.Reward = float(self._host("metrics")[0])
         return (self.Reward, self.DataBuf, self.data_t, self.data_p, self._host("over_power"), self.over_data)
