@@ -674,6 +674,269 @@ k_bcd_sweep8_idx(Dims d, const double* __restrict__ c_col, float* __restrict__ t
 }
 
 // ---------------------------------------------------------------------------
+// k_bcd_sweep8_pair: the indexed sweep with TWO LANES PER ENV (round 3).
+//
+// k_bcd_sweep8_idx gives 32 768 envs 512 wavefronts -- half of the chip's 1 024 SIMDs have none -- and a lone
+// wavefront issues one instruction per 4 (float32 / integer) or 8 (float64) cycles whatever its dependencies, so
+// the sweep time is (instructions per coordinate) x M.  Here the even lane of a pair owns the real part of the
+// running sum S, the odd lane the imaginary part: each of the three complex products of a coordinate
+// (rest = S - cand_old c, w = conj(rest) c, S' = rest + cand_new c) costs a lane 2 float64 instructions instead
+// of 4, the halves meet through DPP quad permutes (lane ^ 1: plain VALU, no LDS), each lane evaluates ONE side
+// of the octant test, and the tile epilogue (float32 image + index of the winner, theta / index stores) is split
+// between the two lanes.  32 envs per wavefront: 1 024 wavefronts at BASELINE configs[4], one per SIMD.
+//
+// Per-lane operands that make both lanes run the SAME instructions (hb = lane & 1; c = (cx, cy)):
+//   cys          = cy (hb = 0) / -cy (hb = 1)                      one XOR on the high word per coordinate
+//   (p1, p2)     = (px, -py) / (py, -px)  of the old phasor         from a per-lane LDS table
+//   rest_self    = S_self - p1 cx - p2 cys
+//   w_self       = rest_self cx + rest_other cys                    = Re q / -Im q  (q = conj(rest) c): the winner
+//                                                                     is the multiple of 45 deg nearest to (w_0, w_1)
+//   along_self   = |w_other| <= tan(pi/8) |w_self|                  the winner lies on this lane's axis
+//   n_self       = +-1 (along_self) | 0 (along_other only) | +-r (neither), sign of w_self
+//   S'_self      = rest_self + n_self cx - n_other cys
+// q = 0 (every candidate ties -> the first wins, ENV:210-218) and S' = 0 (no candidate scores above 0 -> the
+// integer 0, ENV:211, 220) are detected off the chain (one v_min3 on high words per coordinate) and the tile is
+// replayed exactly, as in k_bcd_sweep8_idx.  Decisions equal that kernel's wherever best and second-best
+// candidate differ by more than float64 rounding (the imaginary parts fuse their products in another order).
+// ---------------------------------------------------------------------------
+struct PairOld { double p1, p2; };                          // 16 bytes
+struct PairOut { float cr, ci; int k, pad; };               // 16 bytes
+
+__device__ __forceinline__ int dpp_x1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); }
+
+template <bool PAD, bool STAMP = false>
+__global__ void __launch_bounds__(kWave)
+k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
+                  int32_t* __restrict__ idx_out, double* __restrict__ s_sum, int reuse_s,
+                  uint8_t* __restrict__ theta_idx) {
+    __shared__ PairOld s_old[2][16];                        // [hb][k]; k = 8 (and up): the integer 0
+    __shared__ PairOut s_out[2][16];                        // [hb][code]; code = piece_self | piece_other << 2, piece = along << 1 | negative
+    constexpr int HALF = kWave / 2;                         // envs per wavefront
+    constexpr unsigned ONE_HI = 0x3FF00000u, R_HI = 0x3FE6A09Eu, R_LO = 0x667F3BCDu;     // 1.0, 0.70710678118654757
+    const int M = d.M;
+    const int lane = threadIdx.x, hb = lane & 1, ei = lane >> 1;
+    if (lane < 32) {
+        const double r = 0.70710678118654757;              // cos(pi/4) as numpy rounds it
+        const double cr[9] = {1.0, r, 0.0, -r, -1.0, -r, 0.0, r, 0.0};
+        const double ci[9] = {0.0, r, 1.0, r, 0.0, -r, -1.0, -r, 0.0};
+        const int t_hb = lane >> 4, id = lane & 15;
+        const int kc = id < 9 ? id : 8;
+        s_old[t_hb][id] = t_hb ? PairOld{ci[kc], -cr[kc]} : PairOld{cr[kc], -ci[kc]};
+        const int ps = id & 3, po = id >> 2;
+        const int xp = t_hb ? po : ps, yp = t_hb ? ps : po;
+        const bool ax = xp >> 1, sx = xp & 1, ay = yp >> 1, sy = yp & 1;   // sx / sy: w_0 / w_1 negative
+        int k;
+        if (ax && ay) k = 0;                                // q = 0: replayed; the first index
+        else if (ax) k = sx ? 4 : 0;
+        else if (ay) k = sy ? 6 : 2;
+        else k = sx ? (sy ? 5 : 3) : (sy ? 7 : 1);
+        s_out[t_hb][id] = PairOut{(float)cr[k], (float)ci[k], k, 0};
+    }
+    __syncthreads();
+    const long long e0 = (long long)blockIdx.x * HALF;
+    const bool live = e0 + ei < d.E;
+    const long long e = live ? e0 + ei : d.E - 1;
+    const long long slab = blockIdx.x >> 1;
+    const int sl = (blockIdx.x & 1) * HALF + ei;            // this env's lane in its 64-env slab
+    const double2* __restrict__ cg = reinterpret_cast<const double2*>(c_col) + slab * M * kWave + sl;
+    const int n_blk = (M + kSweepBlk - 1) / kSweepBlk;
+    uint8_t* __restrict__ ig = theta_idx + idx8_off(slab, n_blk, 0, sl);
+    const unsigned sgn = (unsigned)hb << 31;
+    const PairOld* __restrict__ told = s_old[hb];
+    const PairOut* __restrict__ tout = s_out[hb];
+
+    struct Tile {
+        double2 c[kSweepBlk];
+        uint2 k;
+    };
+    auto fetch = [&](Tile& t, int kb) {
+        const int kbc = kb < n_blk ? kb : n_blk - 1;           // past the end: harmless re-read of the last tile
+#pragma unroll
+        for (int j = 0; j < kSweepBlk; ++j)
+            t.c[j] = cg[(long long)(PAD ? min(kbc * kSweepBlk + j, M - 1) : kbc * kSweepBlk + j) * kWave];
+        t.k = *reinterpret_cast<const uint2*>(ig + (long long)kbc * kWave * 8);
+    };
+    auto old_of = [&](const Tile& t, int j) -> PairOld { return told[((j < 4 ? t.k.x : t.k.y) >> (8 * (j & 3))) & 15u]; };
+    auto flip = [&](double cy) { return __hiloint2double(__double2hiint(cy) ^ (int)sgn, __double2loint(cy)); };
+
+    // ---- pass 1 (only when the cached sum is not current): S_self = sum_m p1 cx + p2 cys
+    double S = 0.0;
+    if (reuse_s) {
+        S = s_sum[e * 2 + hb];
+    } else {
+        double T = 0.0;
+        Tile ta, tb;
+        auto sum_tile = [&](int kb, const Tile& cur, Tile& nxt) {
+            fetch(nxt, kb + 1);
+#pragma unroll
+            for (int j = 0; j < kSweepBlk; j += 2) {
+                const bool ok0 = !PAD || kb * kSweepBlk + j < M, ok1 = !PAD || kb * kSweepBlk + j + 1 < M;
+                const PairOld a = ok0 ? old_of(cur, j) : told[8], b2 = ok1 ? old_of(cur, j + 1) : told[8];
+                S = fma(a.p1, cur.c[j].x, S); S = fma(a.p2, flip(cur.c[j].y), S);
+                T = fma(b2.p1, cur.c[j + 1].x, T); T = fma(b2.p2, flip(cur.c[j + 1].y), T);
+            }
+        };
+        fetch(ta, 0);
+        for (int kb = 0; kb < n_blk; kb += 2) {
+            sum_tile(kb, ta, tb);
+            if (kb + 1 < n_blk) sum_tile(kb + 1, tb, ta);
+        }
+        S += T;
+    }
+
+    // ---- pass 2: the chain
+    long long t_chain = 0, t_epi = 0, t_all = 0;
+    if constexpr (STAMP) t_all = -(long long)__builtin_amdgcn_s_memtime();
+    // this lane's half of its env's 64-byte theta tile (coordinates 4 hb .. 4 hb + 3) and of the index word
+    float4* __restrict__ trow4 = reinterpret_cast<float4*>(theta + e * (long long)M * 2) + 2 * hb;
+    float2* __restrict__ trow2 = reinterpret_cast<float2*>(theta + e * (long long)M * 2) + 4 * hb;
+    const double tn = 0.41421356237309503;                  // tan(pi/8)
+    auto chain_tile = [&](int kb, Tile& cur, Tile& nxt, int ahead) {
+        fetch(nxt, kb + ahead);
+        if constexpr (STAMP) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            t_chain -= (long long)__builtin_amdgcn_s_memtime();
+        }
+        // the tile image becomes (cx, cys) in place: one XOR per coordinate, no copy of the low word
+#pragma unroll
+        for (int j = 0; j < kSweepBlk; ++j) cur.c[j].y = flip(cur.c[j].y);
+        const double S0 = S;
+        PairOld po[kSweepBlk];
+#pragma unroll
+        for (int j = 0; j < kSweepBlk; ++j) po[j] = old_of(cur, j);
+        unsigned acc = 0;                                   // (along_self, w_self < 0) of the 8 coordinates, coordinate 0 on top
+        float zmin = 1.0f;                                  // reaches 0 when some w_self or S'_self is (as good as) zero
+#pragma unroll
+        for (int j = 0; j < kSweepBlk; ++j) {
+            const bool ok = !PAD || kb * kSweepBlk + j < M;  // wave-uniform; elements past M leave S alone
+            const double cx = ok ? cur.c[j].x : 0.0, cys = ok ? cur.c[j].y : 0.0;   // (the tile holds cys: flipped below)
+            double r = fma(-po[j].p1, cx, S);
+            r = fma(-po[j].p2, cys, r);
+            const double r_o = xchg<1>(r);
+            const double w = fma(r_o, cys, r * cx);
+            const double w_o = xchg<1>(w);
+            // masks instead of booleans: every select below is one v_bfi / v_and_or, no scalar-mask logic on the chain
+            const unsigned am = fabs(w_o) <= tn * fabs(w) ? ~0u : 0u;          // the winner lies along this lane's axis
+            const unsigned bm = (unsigned)dpp_x1((int)am);                      // ... along the other lane's axis
+            const unsigned whi = (unsigned)__double2hiint(w);
+            const unsigned nlo = ~(am | bm) & R_LO;
+            const unsigned mag = (am & ONE_HI) | (~am & (~bm & R_HI));          // 1 | 0 | r  (both masks set: q = 0, replayed)
+            const unsigned nhi = (whi & 0x80000000u) | mag;                     // a signed zero is as good as zero here
+            const double n_s = __hiloint2double((int)nhi, (int)nlo);
+            const double n_o = __hiloint2double(dpp_x1((int)nhi), (int)nlo);
+            S = fma(n_s, cx, r);
+            S = fma(-n_o, cys, S);
+            float z3;
+            asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(z3) : "v"(zmin), "v"(whi), "v"(__double2hiint(S)));
+            zmin = ok ? z3 : zmin;
+            acc = __builtin_amdgcn_alignbit(acc, am, 31);    // (acc << 1) | along
+            acc = __builtin_amdgcn_alignbit(acc, whi, 31);   // (acc << 1) | sign bit of w
+        }
+        // epilogue: this lane's four coordinates (4 hb + s): code -> float32 image and index of the winner
+        float2 out[4];
+        unsigned kw = 0;
+        if (!__any(zmin == 0.f)) {
+            const unsigned acc_o = (unsigned)dpp_x1((int)acc);
+            const unsigned fs = (acc >> (hb ? 0 : 8)) & 0xFFu, fo = (acc_o >> (hb ? 0 : 8)) & 0xFFu;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned code = ((fs >> (2 * (3 - s))) & 3u) | (((fo >> (2 * (3 - s))) & 3u) << 2);
+                const PairOut en = tout[code];
+                out[s] = make_float2(en.cr, en.ci);
+                kw |= (unsigned)en.k << (8 * s);
+            }
+        } else {
+            // q = 0 (all candidates tie: the first wins) or S' = 0 (no candidate scores above 0: the integer 0,
+            // ENV:211, 220) somewhere in this tile: replay it exactly from the saved start state
+            S = S0;
+            float2 o8[kSweepBlk];
+            unsigned k8[kSweepBlk];
+#pragma unroll
+            for (int j = 0; j < kSweepBlk; ++j) {
+                const bool ok = !PAD || kb * kSweepBlk + j < M;
+                const PairOld p = old_of(cur, j);
+                const double cx = ok ? cur.c[j].x : 0.0, cys = ok ? cur.c[j].y : 0.0;
+                double r = fma(-p.p1, cx, S);
+                r = fma(-p.p2, cys, r);
+                const double r_o = xchg<1>(r);
+                const double w = fma(r_o, cys, r * cx);
+                const double w_o = xchg<1>(w);
+                const bool along = fabs(w_o) <= tn * fabs(w);
+                const bool along_o = dpp_x1(along ? 1 : 0) != 0;
+                const bool tie = along && along_o;           // w = 0: k = 0, the phasor (1, 0)
+                const int neg = (int)((unsigned)__double2hiint(w) >> 31), neg_o = dpp_x1(neg);
+                // (both lanes "along" -> the table's k = 0 entry whatever the signs of the zeros)
+                const unsigned code = ((along ? 2u : 0u) | (unsigned)neg) | (((along_o ? 2u : 0u) | (unsigned)neg_o) << 2);
+                const PairOut en = tout[code];
+                // this lane's component of the winner, exact float64
+                const double rr = 0.70710678118654757;
+                double n_se = along ? (neg ? -1.0 : 1.0) : (along_o ? 0.0 : (neg ? -rr : rr));
+                n_se = tie ? (hb ? 0.0 : 1.0) : n_se;
+                const double n_oe = xchg<1>(n_se);
+                double nS = fma(n_se, cx, r);
+                nS = fma(-n_oe, cys, nS);
+                const bool z_s = nS == 0.0, z_o = dpp_x1(z_s ? 1 : 0) != 0;
+                const bool none = ok && z_s && z_o;          // no candidate scores above 0
+                S = none ? r : nS;
+                o8[j] = none ? make_float2(0.f, 0.f) : make_float2(en.cr, en.ci);
+                k8[j] = none ? 8u : (unsigned)en.k;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                out[s] = hb ? o8[s + 4] : o8[s];
+                kw |= (hb ? k8[s + 4] : k8[s]) << (8 * s);
+            }
+        }
+        if constexpr (STAMP) {
+            asm volatile("" ::"v"(S), "v"(acc));
+            const long long now = (long long)__builtin_amdgcn_s_memtime();
+            t_chain += now;
+            t_epi -= now;
+        }
+        if (live) {
+            if (!PAD) {
+                trow4[kb * 4] = make_float4(out[0].x, out[0].y, out[1].x, out[1].y);
+                trow4[kb * 4 + 1] = make_float4(out[2].x, out[2].y, out[3].x, out[3].y);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (kb * kSweepBlk + 4 * hb + s < M) trow2[kb * kSweepBlk + s] = out[s];
+            }
+        }
+        *reinterpret_cast<unsigned*>(ig + (long long)kb * kWave * 8 + 4 * hb) = kw;
+        if (!STAMP && idx_out && live) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int m = kb * kSweepBlk + 4 * hb + s;
+                const unsigned kn = (kw >> (8 * s)) & 15u;
+                if (m < M) idx_out[e * M + m] = kn == 8u ? -1 : (int)kn;
+            }
+        }
+        if constexpr (STAMP) t_epi += (long long)__builtin_amdgcn_s_memtime();
+    };
+    {
+        Tile t0, t1, t2, t3;                               // a ring of four tile images, three tiles ahead of the chain
+        fetch(t0, 0); fetch(t1, 1); fetch(t2, 2);
+        for (int kb = 0; kb < n_blk; kb += 4) {
+            chain_tile(kb, t0, t3, 3);
+            if (kb + 1 < n_blk) chain_tile(kb + 1, t1, t0, 3);
+            if (kb + 2 < n_blk) chain_tile(kb + 2, t2, t1, 3);
+            if (kb + 3 < n_blk) chain_tile(kb + 3, t3, t2, 3);
+        }
+    }
+    if (live && s_sum) s_sum[e * 2 + hb] = S;
+    if constexpr (STAMP) {
+        t_all += (long long)__builtin_amdgcn_s_memtime();
+        if (lane == 0 && idx_out) {
+            idx_out[blockIdx.x * 4 + 0] = (int)t_chain;
+            idx_out[blockIdx.x * 4 + 1] = (int)t_epi;
+            idx_out[blockIdx.x * 4 + 2] = (int)t_all;
+            idx_out[blockIdx.x * 4 + 3] = n_blk;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 hipError_t launch_colsum(const RisVecState& s, hipStream_t st) {
@@ -724,10 +987,29 @@ hipError_t launch_bcd(const RisVecState& s, const RisVecParams&, int32_t* idx_ou
     }
     if (s.control_bit == 3 && reuse_idx && s.theta_idx && !idx_sweep_disabled()) {
         const unsigned grid = (unsigned)((s.n_envs + kWave - 1) / kWave);
-        static const bool stamps = std::getenv("RISVEC_SWEEP_STAMPS") != nullptr;
-        if (stamps && idx_out && s.n_ris % kSweepBlk == 0) {            // diagnostic build, see the kernel
-            hipLaunchKernelGGL((k_bcd_sweep8_idx<false, true>), dim3(grid), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta,
-                               idx_out, s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
+#ifdef RISVEC_DIAG
+        // diagnostic library only (make diag -> librisvec_diag.so, tools/sweep_stamps.py): the s_memtime builds of the sweeps
+        static const char* stamps = std::getenv("RISVEC_SWEEP_STAMPS");        // "pair" / "idx"
+        if (stamps && idx_out && s.n_ris % kSweepBlk == 0) {
+            if (stamps[0] == 'i')
+                hipLaunchKernelGGL((k_bcd_sweep8_idx<false, true>), dim3(grid), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta,
+                                   idx_out, s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
+            else
+                hipLaunchKernelGGL((k_bcd_sweep8_pair<false, true>), dim3((unsigned)((s.n_envs + kWave / 2 - 1) / (kWave / 2))),
+                                   dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out, s.s_sum,
+                                   (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
+            return hipGetLastError();
+        }
+#endif
+        static const bool no_pair = std::getenv("RISVEC_NO_PAIR_SWEEP") != nullptr;   // A/B switch: one lane per env
+        if (!no_pair) {
+            const unsigned gp = (unsigned)((s.n_envs + kWave / 2 - 1) / (kWave / 2));
+            if (s.n_ris % kSweepBlk)
+                hipLaunchKernelGGL(k_bcd_sweep8_pair<true>, dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out,
+                                   s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
+            else
+                hipLaunchKernelGGL(k_bcd_sweep8_pair<false>, dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out,
+                                   s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
             return hipGetLastError();
         }
         if (s.n_ris % kSweepBlk)

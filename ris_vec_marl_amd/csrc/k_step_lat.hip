@@ -302,7 +302,9 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
     const int epwt = lat_epwt(s.n_envs, epw);
     if (epwt <= 0) return hipErrorNotSupported;
     const RisVecTraj none{nullptr, nullptr, nullptr};
-    if (const char* dbg = std::getenv("RISVEC_LAT_STAMPS_PTR")) {      // diagnostic build, tools/lat_stamps.py
+#ifdef RISVEC_DIAG
+    // diagnostic library only (make diag -> librisvec_diag.so, tools/lat_stamps.py): the s_memrealtime build of the kernel
+    if (const char* dbg = std::getenv("RISVEC_LAT_STAMPS_PTR")) {
         if (s.n_veh == 8 && s.n_ris == 36 && epwt == 2) {
             const RisVecTraj tj{reinterpret_cast<float*>(std::strtoull(dbg, nullptr, 0)), nullptr, nullptr};
             const long long waves = ((long long)s.n_envs + 1) / 2;
@@ -311,6 +313,7 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
             return hipGetLastError();
         }
     }
+#endif
     return dispatch_lat<false>(s, p, a, 1, none, epwt, st);
 }
 

@@ -2,7 +2,10 @@
 """Diagnostic: per-wavefront timeline of the latency-shaped fused step at BASELINE configs[1] (4 096 x 8 x 36):
 s_memrealtime (100 MHz) at entry / loads issued / cascade reduced / step() done / stores drained."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the stamp build lives in the DIAGNOSTIC library only (make -C ris_vec_marl_amd/csrc diag)
+os.environ["RISVEC_LIB"] = os.path.join(ROOT, "ris_vec_marl_amd", "csrc", "librisvec_diag.so")
+sys.path.insert(0, ROOT)
 import numpy as np, torch
 from bench import build_env, synthetic_groups
 E, V, M = 4096, 8, 36

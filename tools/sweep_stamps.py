@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""Diagnostic: where the cycles of the indexed BCD sweep go (RISVEC_SWEEP_STAMPS build of k_bcd_sweep8_idx):
-per wavefront, s_memtime cycles inside the 8-coordinate chain vs the tile epilogue (theta / index stores)."""
+"""Diagnostic: where the cycles of the indexed BCD sweep go (s_memtime builds of k_bcd_sweep8_pair / k_bcd_sweep8_idx in
+the DIAGNOSTIC library, `make -C ris_vec_marl_amd/csrc diag`): per wavefront, cycles inside the 8-coordinate chain vs
+the tile epilogue (theta / index stores).  Usage: sweep_stamps.py [E V M] [pair|idx]"""
 import json, os, sys
-os.environ["RISVEC_SWEEP_STAMPS"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KIND = sys.argv[4] if len(sys.argv) > 4 else "pair"
+os.environ["RISVEC_SWEEP_STAMPS"] = KIND
+os.environ["RISVEC_LIB"] = os.path.join(ROOT, "ris_vec_marl_amd", "csrc", "librisvec_diag.so")
+sys.path.insert(0, ROOT)
 import numpy as np, torch
 from bench import build_env
 E, V, M = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (32768, 16, 256)))
@@ -12,9 +16,10 @@ env.optimize_phase_shift()                      # generic kernel: leaves the ind
 for _ in range(3):
     idx = env.optimize_phase_shift(return_idx=True)
 torch.cuda.synchronize()
-a = idx.cpu().numpy().reshape(-1)[: 4 * ((E + 63) // 64)].reshape(-1, 4).astype(np.float64)
+EPW = 32 if KIND[0] == 'p' else 64          # envs per wavefront
+a = idx.cpu().numpy().reshape(-1)[: 4 * ((E + EPW - 1) // EPW)].reshape(-1, 4).astype(np.float64)
 nb = a[0, 3]
-print(json.dumps(dict(E=E, V=V, M=M, waves=int(a.shape[0]), tiles=int(nb),
+print(json.dumps(dict(kernel=KIND, E=E, V=V, M=M, waves=int(a.shape[0]), tiles=int(nb),
                       chain_cycles_per_coordinate=float(np.median(a[:, 0]) / (nb * 8)),
                       epilogue_cycles_per_coordinate=float(np.median(a[:, 1]) / (nb * 8)),
                       total_cycles_per_coordinate=float(np.median(a[:, 2]) / (nb * 8)),
