@@ -47,6 +47,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     constexpr int VP = S::VP, NP = S::NP, G = S::G, NIT = S::NIT, VPP = S::VPP;
     constexpr int PC = S::PC, CHUNKS = S::CHUNKS, K = S::K;
     constexpr int NU = EPWT * CHUNKS;                          // load units of the wavefront's envs
+    constexpr bool EARLY_PRE = !MULTI && EPWT <= 2;            // step_pre in the shadow of the memory round trip
     static_assert(EPWT >= 1 && EPWT <= S::EPW, "a wavefront holds at most 64/VP envs");
     __shared__ float s_img[kBlock / kWave][kWave * 2];
 
@@ -97,6 +98,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     constexpr int UB = NU > 4 ? 4 : NU;
     static_assert(NU % UB == 0, "unit batches must tile the wavefront's units");
     float2 w0[NIT], w1[NIT];
+    StepPre pre{};
 #pragma unroll
     for (int b0 = 0; b0 < NU; b0 += UB) {
         Unit<PC, NIT> u[UB];
@@ -121,6 +123,15 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
                     u[k].t[it] = lat_ld<NT>(tb + pcl[it]);
                 }
             }
+        }
+        // The gain-independent third of step() (action map, projection, local CPU terms, the Philox / Poisson arrival
+        // draw) runs HERE, behind the last request and in front of the first wait on h_r: its inputs were requested
+        // first and arrive first, and the SIMD has nothing else to issue until the rows are back.
+        // (one or two envs per wavefront only: with four, rows of the first env are back before the last request has
+        // left, the reduce has to start consuming them at once, and the same instructions in front of it measured
+        // +7 % at the BASELINE configs[3] shard)
+        if constexpr (EARLY_PRE) {
+            if (b0 == 0) pre = step_pre(d, P, A, e_mine, v_mine, active, in);
         }
         // 16 x 256 (one env = 34 loads per lane): left alone the compiler starts reducing before the last request is
         // out, to stay at 123 registers; with every request up front (168 registers, 3 wavefronts per SIMD) BASELINE
@@ -166,8 +177,9 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
         g = gain_from_img(img, in.pl, A.h_d, idx);
         A.gain[idx] = g;
     }
+    if constexpr (!EARLY_PRE && !MULTI) pre = step_pre(d, P, A, e_mine, v_mine, active, in);
     if constexpr (STAMP) {
-        step_core<VP, false, true>(d, P, A, e_mine, v_mine, active, g, in);
+        step_tail<VP, false, true>(d, P, A, e_mine, v_mine, active, g, in, pre);
         asm volatile("" ::: "memory");
         ts[3] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -177,7 +189,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
             dbg[0] = ts[0]; dbg[1] = ts[1]; dbg[2] = ts[2]; dbg[3] = ts[3]; dbg[4] = ts[4];
         }
     } else if constexpr (!MULTI) {
-        step_core<VP, false, true>(d, P, A, e_mine, v_mine, active, g, in);
+        step_tail<VP, false, true>(d, P, A, e_mine, v_mine, active, g, in, pre);
     } else {
         multi_step_loop<VP>(d, P, A, TJ, e_mine, v_mine, active, g, in, n_steps);
     }

@@ -51,7 +51,7 @@ struct MarlCore {
         return load_step_in(d, A, e, v, active);
     }
     static __device__ __forceinline__ void hold(const In& in) {
-        asm volatile("" ::"v"(in.a0), "v"(in.a1), "v"(in.B), "v"(in.Q0), "v"(in.pl), "v"(in.part), "v"(in.G));
+        asm volatile("" ::"v"(in.a0), "v"(in.a1), "v"(in.B), "v"(in.Q0), "v"(in.pl), "v"(in.part), "v"(in.G), "v"(in.arr_in));
     }
     template <int VP>
     static __device__ __forceinline__ void run(const Dims& d, const Params& P, const Args& A, int e, int v,

@@ -137,7 +137,7 @@ __device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_a
 // result, so a 5-term log1p series is used there; above it v_log_f32(1 + x).
 __device__ __forceinline__ float log2_1p(float x) {
     const float big = __builtin_amdgcn_logf(1.0f + x);
-    const float ser = x * (1.f + x * (-0.5f + x * (0.33333334f + x * (-0.25f + x * 0.2f))));
+    const float ser = x * fmaf(x, fmaf(x, fmaf(x, fmaf(x, 0.2f, -0.25f), 0.33333334f), -0.5f), 1.f);
     return x < 0.0625f ? ser * 1.4426950408889634f : big;
 }
 
@@ -145,10 +145,17 @@ __device__ __forceinline__ float log2_1p(float x) {
 struct StepIn {
     float a0, a1, B, Q0, pl;
     int part, G;
+    int arr_in;              // injected arrivals (ignored when the draw is Philox)
 };
 
+// Where a lane's injected arrival count lives -- ALWAYS a valid address: without injected arrivals the lane re-reads
+// its `partner` word (same cache line as the load next to it, value ignored).  A load under `if (A.arrivals)` is a
+// branch around a request, and the compiler can only join the two paths with `s_waitcnt vmcnt(0)`: a full drain of
+// every h_r request in flight, in front of the arithmetic that was supposed to hide under them.
+__device__ __forceinline__ const int32_t* arrivals_src(const StepArgs& A) { return A.arrivals ? A.arrivals : A.partner; }
+
 __device__ __forceinline__ StepIn load_step_in(const Dims& d, const StepArgs& A, int e, int v, bool active) {
-    StepIn in{0.f, 0.f, 0.f, 0.f, 0.f, RISVEC_PARTNER_NONE, 1};
+    StepIn in{0.f, 0.f, 0.f, 0.f, 0.f, RISVEC_PARTNER_NONE, 1, 0};
     if (active) {
         const int V = d.V;
         const long long idx = (long long)e * V + v;
@@ -162,6 +169,7 @@ __device__ __forceinline__ StepIn load_step_in(const Dims& d, const StepArgs& A,
         }
         in.B = A.data_buf[idx];
         in.part = A.partner[idx];
+        in.arr_in = arrivals_src(A)[idx];
         in.G = A.n_groups[e];
         in.Q0 = A.mec_q[e];
         in.pl = A.pl ? A.pl[idx] : 0.f;
@@ -173,6 +181,7 @@ __device__ __forceinline__ StepIn load_step_in(const Dims& d, const StepArgs& A,
 // near = u1 if gain1 > gain2 else u2 (ENV:355-360): a vehicle listed second is "near" on ties.
 template <int VP>
 __device__ __forceinline__ float noma_rate(const RisVecParams& P, float pw0, float gain, int part, int G) {
+#pragma clang fp contract(off)     // fused products are written out (fmaf): no rounding may depend on the calling kernel
     const int lane = threadIdx.x & (kWave - 1);
     const int base = lane & ~(VP - 1);
     const bool pair = part >= 0, single = part == RISVEC_PARTNER_SINGLE;
@@ -182,7 +191,7 @@ __device__ __forceinline__ float noma_rate(const RisVecParams& P, float pw0, flo
     const float pw_p = __shfl(pw0, src, kWave);
     const bool near = second ? !(g_p > gain) : (gain > g_p);
     const float sig = pw0 * gain;                                            // ENV:347, 362, 367
-    const float den = (pair && !near) ? (pw_p * gain + P.noise_power) : P.noise_power;   // ENV:363-364
+    const float den = (pair && !near) ? fmaf(pw_p, gain, P.noise_power) : P.noise_power;   // ENV:363-364
     const float sinr = fdiv(sig, den);
     const float frac = __builtin_amdgcn_rcpf((float)max(1, G));              // ENV:341-342
     const float rate = frac * log2_1p(sinr);
@@ -274,22 +283,39 @@ struct StepCarry {
 };
 
 // ---------------------------------------------------------------------------
-// step() for one (env, vehicle) lane.  Called by ALL 64 lanes (cross-lane ops inside);
-// `active` masks lanes beyond V or E.  TRAJ = false is the single-step form (every output
-// goes to the env's tensors); TRAJ = true additionally honours `tj`.
-// ---------------------------------------------------------------------------
+// step() for one (env, vehicle) lane, in two halves (round 3):
+//   step_pre   everything that does NOT depend on the channel gain -- action map, power projection, CPU share,
+//              local processing, local energy, the Philox + Poisson arrival draw, over_power.  About a third of
+//              step()'s instructions; the latency-shaped kernels run it while their h_r / theta requests are in
+//              flight (a wavefront there is a chain  issue -> memory round trip -> reduce -> step() -> stores).
+//   step_tail  the rest, from the NOMA rate on.  Called by ALL 64 lanes (cross-lane ops inside); `active` masks
+//              lanes beyond V or E.
+// step_core = step_pre + step_tail back to back: the same operations on the same values whichever kernel calls
+// them in whichever order, so the kernels stay bit-identical (tests/test_entry_points_hip.py).
+// TRAJ = false is the single-step form (every output goes to the env's tensors); TRAJ = true additionally honours `tj`.
 // TM = true: the per-env metrics through one transposing reduction (fewer instructions: the choice of the
 // latency-shaped kernels); TM = false: one butterfly per metric, lane 0 stores four float4 (the software pipeline:
 // its 16-byte stores are a little kinder to a kernel that is busy streaming h_r).  Same values bit for bit.
-template <int VP, bool TRAJ = false, bool TM = false>
-__device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams& P, const StepArgs& A,
-                                               int e, int v, bool active, float gain, const StepIn& in,
-                                               const StepTraj* tj = nullptr) {
-    const int V = d.V;
-    const long long idx = (long long)e * V + v;
-    const float eps = 1e-12f;
-    const float B = in.B, Q0 = in.Q0;
-    const int part = in.part, G = in.G;
+// ---------------------------------------------------------------------------
+struct StepPre {
+    float pw0, pw1;          // transmit / (unused) second power, W                     ENV:555-561
+    float f;                 // local CPU frequency                                      ENV:572-580
+    float bc, cap, used;     // backlog cycles, cycle budget, cycles spent locally       ENV:585-592
+    float data_p, rem;       // kbit processed locally, kbit left for offloading
+    float E_loc;             // local energy                                             ENV:664
+    float over_power;        //                                                          ENV:721
+    float arr_kbit;          // this step's arrivals                                     ENV:717-719
+};
+
+// ARR_LATE (the T-step loop): the arrival draw is left to step_tail, at the place step() has it.  There the injected
+// arrivals are loaded under `if (A.arrivals)`, whose join costs an `s_waitcnt vmcnt(0)`: late in the step that is free,
+// at the top of the step it would wait for the next step's action prefetch every step (measured: +14 % per step).
+template <bool ARR_LATE = false>
+__device__ __forceinline__ StepPre step_pre(const Dims& d, const RisVecParams& P, const StepArgs& A, int e, int v,
+                                            bool active, const StepIn& in) {
+#pragma clang fp contract(off)     // see step_tail
+    StepPre r;
+    const float B = in.B;
     float a0 = in.a0, a1 = in.a1;
 
     // ENV:574-577
@@ -311,31 +337,68 @@ __device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams
         c0 = c0 * inv;
         c1 = c1 * inv;
     }
-    const float pw0 = c0 * P.p_max, pw1 = c1 * P.p_max;
+    r.pw0 = c0 * P.p_max;
+    r.pw1 = c1 * P.p_max;
+
+    // (3) cpu share, ENV:572-580
+    const float cpu = fmaxf(fminf(fmaxf(a1, 0.f), 1.f), fl);
+    r.f = cpu * P.f_local_max;
+    const float Cpb = P.cycles_per_bit, tf = P.time_fast;
+
+    // (4) local processing, ENV:585-592
+    // When the CPU can clear the whole backlog, data_p = bc / (Cpb*1000) equals B up to
+    // rounding (1e-16 in the float64 reference).  In float32 that rounding (1e-7 B) would
+    // leak into `rem`, `off` and t_tx = off / throughput, so the identity is used directly.
+    r.bc = B * 1000.0f * Cpb;
+    r.cap = r.f * tf;
+    const bool clears = r.cap >= r.bc;
+    r.used = clears ? r.bc : r.cap;
+    r.data_p = clears ? B : fdiv(r.cap, Cpb * 1000.0f);
+    r.rem = fmaxf(0.f, B - r.data_p);                                       // ENV:595
+
+    r.E_loc = P.k_cpu * (r.f * r.f) * r.used;                                // ENV:664
+
+    // (12) arrivals, ENV:717-719
+    // The Philox draw is the production path and must be the FALL-THROUGH: a null-pointer test is predicted "unlikely",
+    // which put the draw out of line -- two taken branches (two instruction-fetch restarts) per step for a lone wavefront.
+    int arr = 0;
+    if constexpr (!ARR_LATE) {
+        if (__builtin_expect(A.arrivals == nullptr, 1)) {
+            const uint4 x = philox4x32_10((uint32_t)(d.env_offset + e), (uint32_t)v, A.counter, kSiteArrivals, A.seed);
+            arr = poisson_from_u(u01(x.x), P.poisson_cdf);
+        } else {
+            arr = in.arr_in;
+        }
+    }
+    r.arr_kbit = (float)arr * tf * 1000.0f;
+
+    r.over_power = fmaxf(0.f, (r.pw0 + r.pw1) - P.p_max);                     // ENV:721
+    return r;
+}
+
+template <int VP, bool TRAJ = false, bool TM = false>
+__device__ __forceinline__ StepCarry step_tail(const Dims& d, const RisVecParams& P, const StepArgs& A,
+                                               int e, int v, bool active, float gain, const StepIn& in,
+                                               const StepPre& pre, const StepTraj* tj = nullptr) {
+    // No implicit contraction: whether `a * b + c` became one fused instruction used to depend on what else the
+    // compiler saw around it (the early step_pre of the latency-shaped kernels vs the back-to-back form of the
+    // software pipeline), and the kernels must agree to the last bit.  The fusions worth having are written out.
+#pragma clang fp contract(off)
+    const int V = d.V;
+    const long long idx = (long long)e * V + v;
+    const float eps = 1e-12f;
+    const float B = in.B, Q0 = in.Q0;
+    const int part = in.part, G = in.G;
+    const float pw0 = pre.pw0, f = pre.f, bc = pre.bc, cap = pre.cap, used = pre.used, data_p = pre.data_p;
+    const float Cpb = P.cycles_per_bit;
 
     // (2) rate, ENV:331-372
     const float rate = noma_rate<VP>(P, pw0, gain, part, G);
     const float tf = P.time_fast, bw = P.bandwidth_mhz;
     const float data_t = rate * tf * bw * 1000.0f;                          // ENV:570
 
-    // (3) cpu share, ENV:572-580
-    const float cpu = fmaxf(fminf(fmaxf(a1, 0.f), 1.f), fl);
-    const float f = cpu * P.f_local_max;
-    const float Cpb = P.cycles_per_bit;
-
-    // (4) local processing, ENV:585-592
-    // When the CPU can clear the whole backlog, data_p = bc / (Cpb*1000) equals B up to
-    // rounding (1e-16 in the float64 reference).  In float32 that rounding (1e-7 B) would
-    // leak into `rem`, `off` and t_tx = off / throughput, so the identity is used directly.
-    const float bc = B * 1000.0f * Cpb;
-    const float cap = f * tf;
-    const bool clears = cap >= bc;
-    const float used = clears ? bc : cap;
-    const float data_p = clears ? B : fdiv(cap, Cpb * 1000.0f);
-
     // (5) offload, ENV:595-601
-    const float rem = fmaxf(0.f, B - data_p);
-    const float off = fminf(data_t, rem);
+    const float off = fminf(data_t, pre.rem);
     const float thr = rate * bw * 1000.0f;
     const float t_tx = fdiv(off, thr + 1e-12f);
 
@@ -360,7 +423,7 @@ __device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams
 
     // (9) energy, ENV:659-666
     const float E_tx = pw0 * t_tx;
-    const float E_loc = P.k_cpu * (f * f) * used;
+    const float E_loc = pre.E_loc;
     const float energy = E_tx + E_loc;
 
     // (10) QoS, ENV:669-677
@@ -368,22 +431,25 @@ __device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams
     const float pen = viol ? P.qos_penalty : 0.f;
 
     // (11) reward, ENV:696-703
-    const float cost = P.w_d * delay + P.w_e * energy;
+    const float cost = fmaf(P.w_d, delay, P.w_e * energy);
     const float rew = fminf(fmaxf(-cost - pen, -P.reward_clip), P.reward_clip);
 
-    // (12) arrivals, ENV:717-719
-    int arr = 0;
-    if (A.arrivals) {
-        if (active) arr = A.arrivals[idx];
+    // (12) arrivals, ENV:717-719 (drawn in step_pre, except in the T-step loop)
+    if constexpr (TRAJ) {
+        int arr = 0;
+        if (A.arrivals) {
+            if (active) arr = A.arrivals[idx];
+        } else {
+            const uint4 x = philox4x32_10((uint32_t)(d.env_offset + e), (uint32_t)v, A.counter, kSiteArrivals, A.seed);
+            arr = poisson_from_u(u01(x.x), P.poisson_cdf);
+        }
+        Bn += (float)arr * tf * 1000.0f;
     } else {
-        const uint4 r = philox4x32_10((uint32_t)(d.env_offset + e), (uint32_t)v, A.counter,
-                                      kSiteArrivals, A.seed);
-        arr = poisson_from_u(u01(r.x), P.poisson_cdf);
+        Bn += pre.arr_kbit;
     }
-    Bn += (float)arr * tf * 1000.0f;
 
     // (13) ENV:721-729
-    const float over_power = fmaxf(0.f, (pw0 + pw1) - P.p_max);
+    const float over_power = pre.over_power;
     const float inv_v = __builtin_amdgcn_rcpf((float)V);
 
     bool store_state = true;
@@ -492,6 +558,14 @@ __device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams
     return StepCarry{Bn, Q};
 }
 
+template <int VP, bool TRAJ = false, bool TM = false>
+__device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams& P, const StepArgs& A,
+                                               int e, int v, bool active, float gain, const StepIn& in,
+                                               const StepTraj* tj = nullptr) {
+    const StepPre pre = step_pre<TRAJ>(d, P, A, e, v, active, in);
+    return step_tail<VP, TRAJ, TM>(d, P, A, e, v, active, gain, in, pre, tj);
+}
+
 inline StepArgs make_step_args(const RisVecState& s, const float* action, const int32_t* partner,
                                const int32_t* n_groups, const int32_t* arrivals, uint64_t seed,
                                uint32_t counter, uint32_t flags) {
@@ -538,7 +612,8 @@ __device__ __forceinline__ void multi_step_loop(const Dims& d, const RisVecParam
     const long long mt_stride = TJ.metrics ? (long long)d.E * RISVEC_METRICS : 0;
     const long long ar_stride = A.arrivals ? ev : 0;
     // this lane's word(s) of action[t]: [T, E, V, 2] (policy layout) or [T, E, 2, V]
-    const float* ap = A.action + (pol ? idx * 2 : (long long)e * 2 * V + v);
+    // (inactive lanes re-read the action of (env 0, vehicle 0): an address select, not a branch around the two loads)
+    const float* ap = A.action + (active ? (pol ? idx * 2 : (long long)e * 2 * V + v) : 0);
     const long long a1_off = pol ? 1 : V;
     // The last step is peeled: only it writes the env's own tensors, so inside the loop `store_state` is a constant
     // false -- no branch on it, and the eleven output pointers (spilled: the kernel is at the SGPR limit) are not
@@ -548,11 +623,7 @@ __device__ __forceinline__ void multi_step_loop(const Dims& d, const RisVecParam
     for (int t = 0; t + 1 < n_steps; ++t) {
         // next step's action: in flight during this step's arithmetic
         ap += 2 * ev;
-        float a0n = 0.f, a1n = 0.f;
-        if (active) {
-            a0n = ap[0];
-            a1n = ap[a1_off];
-        }
+        const float a0n = ap[0], a1n = ap[a1_off];
         const StepCarry c = step_core<VP, true, true>(d, P, At, e, v, active, g, in, &tj);
         At.counter += 1u;
         At.arrivals += ar_stride;
