@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 13
+#define RISVEC_ABI_VERSION 14
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -61,6 +61,11 @@ enum {
     RISVEC_STEP_REUSE_COLSUM = 16,  /* risvec_step_fused_bcd: c_col is current, skip its rebuild */
     RISVEC_STEP_REUSE_SSUM = 32,    /* risvec_step_fused_bcd: s_sum is current (see RISVEC_BCD_REUSE_SSUM) */
     RISVEC_STEP_REUSE_IDX = 128,    /* risvec_step_fused_bcd: theta_idx is current (see RISVEC_BCD_REUSE_IDX) */
+    RISVEC_STEP_THETA_BY_INDEX = 256, /* risvec_step_fused_bcd (with RISVEC_STEP_REUSE_IDX, control_bit = 3, a shape for
+                                       which risvec_theta_by_index_supported() is 1): theta is kept BY INDEX -- the sweep
+                                       updates state.theta_idx and does not write the complex64 state.theta, the fused
+                                       step expands the indices through a 9-entry table.  Same outputs bit for bit;
+                                       state.theta is stale until risvec_theta_from_index() materialises it. */
     RISVEC_STEP_STEER = 64          /* risvec_step_fused: h_r is the steering vector risvec_geometry wrote
                                        (phases_R_i[v,m] = z_v^m, z_v = exp(-j pi angle_v), ENV:249-253): do not
                                        read it; evaluate sum_m theta_m b_m z^m by Horner in float64 from
@@ -73,9 +78,12 @@ enum {
     RISVEC_BCD_REUSE_COLSUM = 1,   /* caller guarantees c_col matches h_r and b */
     RISVEC_BCD_REUSE_SSUM = 2,     /* caller guarantees theta and c_col are unchanged since the last sweep
                                       wrote s_sum: start from it instead of re-summing theta.c */
-    RISVEC_BCD_REUSE_IDX = 4       /* caller guarantees theta is unchanged since the last sweep wrote theta_idx (the
+    RISVEC_BCD_REUSE_IDX = 4,      /* caller guarantees theta is unchanged since the last sweep wrote theta_idx (the
                                       candidate index of every element): control_bit = 3 then takes the indexed sweep,
-                                      which never reads theta (about half the instructions per coordinate) */
+                                      which never reads theta (two lanes per env, about a third of the instructions per
+                                      coordinate) */
+    RISVEC_BCD_NO_THETA = 8        /* with RISVEC_BCD_REUSE_IDX and control_bit = 3: update theta_idx only, leave the
+                                      complex64 theta to risvec_theta_from_index() */
 };
 
 /* Physics / geometry parameters: the attributes of `Environ` that the driver sets
@@ -165,10 +173,10 @@ typedef struct RisVecState {
     /* steering base z[e,v] = exp(-j pi angle_R[e,v]) in float64 (h_r[e,v,m] = z^m); written by risvec_geometry
        when non-NULL, read by risvec_step_fused with RISVEC_STEP_STEER */
     double *z_r;            /* [E,V]   c128 (may be NULL)                                 */
-    /* BCD cache: candidate index of every theta element as the last sweep left it (8 = the integer 0 of
-       ENV:211, 220), one byte each, in 8-byte words per (64-env slab, 8-element tile, env): word of
-       (e, m) at ((e/64 * ceil(M/8) + m/8) * 64 + e%64) * 8, byte m%8.  ceil(E/64)*64*ceil(M/8)*8 bytes;
-       written by every control_bit = 3 sweep, read with RISVEC_BCD_REUSE_IDX (may be NULL) */
+    /* Candidate index of every theta element as the last sweep left it (0..7 = exp(j 2 pi k / 8), ENV:169, 213;
+       8 = the integer 0 of ENV:211, 220), one byte each, row-major [E][8*ceil(M/8)] (rows padded to whole 8-element
+       tiles); written by every control_bit = 3 sweep, read with RISVEC_BCD_REUSE_IDX / RISVEC_STEP_THETA_BY_INDEX
+       (may be NULL) */
     uint8_t *theta_idx;
 } RisVecState;
 
@@ -210,6 +218,9 @@ enum {
 typedef void *risvec_stream_t;
 
 uint32_t risvec_abi_version(void);
+/* Name of the kernel the calling thread's last risvec_step* / risvec_bcd call dispatched ("" before the first): which
+ * member of the fused-step family a shape / batch size takes is a dispatch decision; tests assert it. */
+const char *risvec_last_kernel(void);
 const char *risvec_last_error(void);
 
 /* Fill `p` with the class defaults of ENV:57-190 and the reference driver's lanes
@@ -255,6 +266,12 @@ int risvec_bcd(const RisVecState *s, const RisVecParams *p, int32_t *idx_out, ui
                risvec_stream_t stream);
 
 /* get_next_phase (ENV:233-239): theta = exp(j*angle), angle [E,M] float32. */
+/* state.theta[e,m] = the complex64 image of candidate state.theta_idx[e,m]: materialises theta after sweeps that kept
+ * it by index (RISVEC_BCD_NO_THETA / RISVEC_STEP_THETA_BY_INDEX).  What those sweeps would have stored, bit for bit. */
+int risvec_theta_from_index(const RisVecState *s, risvec_stream_t stream);
+/* 1 when the fused step has a theta-by-index form for this shape (RISVEC_STEP_THETA_BY_INDEX), else 0 */
+int risvec_theta_by_index_supported(int32_t n_veh, int32_t n_ris);
+
 int risvec_set_phase(const RisVecState *s, const float *angle, risvec_stream_t stream);
 
 /* Random_phase (ENV:203-206): theta = exp(j*possible_angles[idx]); idx [E,M] int32 or

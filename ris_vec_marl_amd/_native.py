@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -24,7 +24,8 @@ STEP_METRICS, STEP_POWER_W, STEP_POLICY_ACTION, STEP_OBS, STEP_REUSE_COLSUM = 1,
 STEP_REUSE_SSUM = 32
 STEP_STEER = 64
 STEP_REUSE_IDX = 128
-BCD_REUSE_COLSUM, BCD_REUSE_SSUM, BCD_REUSE_IDX = 1, 2, 4
+STEP_THETA_BY_INDEX = 256
+BCD_REUSE_COLSUM, BCD_REUSE_SSUM, BCD_REUSE_IDX, BCD_NO_THETA = 1, 2, 4, 8
 
 METRIC_NAMES = (
     "global_reward", "last_off_kbit_sum", "last_local_kbit_sum", "last_mec_queue_cycles",
@@ -128,6 +129,7 @@ LIB_PATH = os.environ.get("RISVEC_LIB") or os.path.join(os.path.dirname(os.path.
 _PROTOS = {
     "risvec_abi_version": (C.c_uint32, []),
     "risvec_last_error": (C.c_char_p, []),
+    "risvec_last_kernel": (C.c_char_p, []),
     "risvec_default_params": (None, [C.POINTER(RisVecParams)]),
     "risvec_reset": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP,
                                C.c_uint64, C.c_uint32, _FP]),
@@ -139,6 +141,8 @@ _PROTOS = {
                                    _FP, _FP, _FP, C.c_uint64, C.c_uint32, _FP]),
     "risvec_colsum": (C.c_int, [C.POINTER(RisVecState), _FP]),
     "risvec_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, C.c_uint32, _FP]),
+    "risvec_theta_from_index": (C.c_int, [C.POINTER(RisVecState), _FP]),
+    "risvec_theta_by_index_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "risvec_set_phase": (C.c_int, [C.POINTER(RisVecState), _FP, _FP]),
     "risvec_random_phase": (C.c_int, [C.POINTER(RisVecState), _FP, C.c_uint64, C.c_uint32, _FP]),
     "risvec_step": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP, _FP, _FP,
@@ -229,6 +233,12 @@ def resolve_device(device):
     if d.type == "cuda" and d.index is None and torch.cuda.is_available():
         d = torch.device("cuda", torch.cuda.current_device())
     return d
+
+
+def last_kernel() -> str:
+    """Name of the kernel the calling thread's last step / BCD call dispatched (risvec_last_kernel)."""
+    k = load().risvec_last_kernel()
+    return k.decode() if k else ""
 
 
 class RisVecError(RuntimeError):

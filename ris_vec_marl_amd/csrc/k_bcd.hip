@@ -28,7 +28,7 @@
 //                 whole envs in LDS was capped by LDS capacity at 38 envs per CU in flight.
 #include <cstdlib>
 
-#include "risvec_step.hpp"
+#include "risvec_pipe.hpp"
 
 namespace risvec {
 
@@ -245,10 +245,10 @@ k_colsum_slab(Dims d, const float* __restrict__ h_r, const float* __restrict__ b
 constexpr int kSweepBlk = 8;                                // elements per tile
 constexpr int kTRow = kSweepBlk + 2;                        // LDS row stride of the theta tile (elements)
 
-// byte offset of the 8-byte index word of (64-env slab, tile kb, lane) in theta_idx
-__device__ __forceinline__ long long idx8_off(long long slab, int n_blk, int kb, int lane) {
-    return ((slab * n_blk + kb) * kWave + lane) * 8;
-}
+// theta_idx: the candidate index of every theta element as the last 2^b = 8 sweep left it (8 = the integer 0 of
+// ENV:211, 220), one byte per element, ROW-MAJOR [E][8 ceil(M / 8)] (round 3: the fused step kernel reads it along m
+// when theta is kept by index, and a sweep reads / writes one 8-byte word per env and tile -- the 64 rows of a
+// wavefront stay in L1 from tile to tile).
 
 template <int NC>
 __global__ void __launch_bounds__(kWave)
@@ -394,14 +394,14 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
                 if (m < M) idx_out[e * M + m] = ko[j];
             }
         }
-        if (theta_idx) {                                  // candidate index per element (8 = the integer 0) for the indexed sweep
+        if (theta_idx && live) {                          // candidate index per element (8 = the integer 0) for the indexed sweep
             unsigned lo = 0, hi = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 lo |= (unsigned)(ko[j] < 0 ? 8 : ko[j]) << (8 * j);
                 hi |= (unsigned)(ko[j + 4] < 0 ? 8 : ko[j + 4]) << (8 * j);
             }
-            *reinterpret_cast<uint2*>(theta_idx + idx8_off(blockIdx.x, n_blk, kb, lane)) = make_uint2(lo, hi);
+            *reinterpret_cast<uint2*>(theta_idx + (e * n_blk + kb) * 8) = make_uint2(lo, hi);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -420,265 +420,16 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
 }
 
 // ---------------------------------------------------------------------------
-// k_bcd_sweep8_idx: the sweep for 2^b = 8 when the candidate INDEX of every element is known
-// (theta_idx, left by the previous sweep).  The generic kernel above spends ~75 vector instructions per
-// coordinate, most of them not on the dependent chain: reading theta back through an LDS transpose,
-// re-snapping its float32 image to the exact float64 phasor, and materialising the octant test's winner
-// with 64-bit selects.  A lone wavefront per SIMD issues one float64 instruction per ~8 cycles whether or
-// not it depends on the previous one, so the sweep time is (instructions per coordinate) x 8 cycles x M:
-// it is the instruction COUNT that has to come down.  Here
-//   * the old phasor comes from a 9-entry LDS table indexed by the stored byte (no theta read at all);
-//   * rest = S - cand_old c and S' = rest + cand_new c are two FMAs per component;
-//   * the octant test yields a 4-bit code (two compares + two sign bits) that indexes a 16-entry LDS table
-//     holding the winner's float64 phasor, its float32 image and its index.
-// ~40 vector instructions per coordinate.  Decisions equal the generic kernel's wherever the best and the
-// second-best candidate differ by more than float64 rounding (the products are fused differently).
-// ---------------------------------------------------------------------------
-// The winner of the octant test as float64 bit patterns, without a table lookup on the dependent chain:
-// nr = 0 (along y) | +-1 (along x) | +-r (diagonal), sign of qr;  ni likewise with the sign of -qi.
-// ax = |qi| <= t |qr|, ay2 = |qr| <= t |qi|; both only for q = 0, where every candidate ties and the first
-// (k = 0: +1) wins whatever the signs of the zeros.
-__device__ __forceinline__ void octant_winner(double qr, double qi, bool ax, bool ay2, double& nr, double& ni) {
-    constexpr unsigned ONE_HI = 0x3FF00000u, R_HI = 0x3FE6A09Eu, R_LO = 0x667F3BCDu;     // 1.0, 0.70710678118654757
-    const unsigned qrh = (unsigned)__double2hiint(qr), qih = (unsigned)__double2hiint(qi);
-    const bool ay_only = ay2 && !ax, both = ax && ay2;
-    const unsigned lo = (ax || ay2) ? 0u : R_LO;
-    unsigned nrh = ((ax ? ONE_HI : R_HI) | (qrh & 0x80000000u));
-    unsigned nih = ((ay_only ? ONE_HI : R_HI) | (~qih & 0x80000000u));
-    nrh = ay_only ? 0u : nrh;
-    nrh = both ? ONE_HI : nrh;
-    nih = ax ? 0u : nih;
-    nr = __hiloint2double((int)nrh, (int)lo);
-    ni = __hiloint2double((int)nih, (int)lo);
-}
-
-struct OctEntry {           // 32 bytes
-    double nr, ni;          // the winning candidate, exact float64
-    float cr, ci;           // its float32 image (what theta stores)
-    int k, pad;             // its index
-};
-
-// STAMP: diagnostic build (RISVEC_SWEEP_STAMPS=1 + an idx_out buffer): instead of the chosen indices, idx_out
-// receives per wavefront {cycles in the chain, cycles in the tile epilogue, total cycles, tiles} from s_memtime.
-template <bool PAD, bool STAMP = false>          // PAD: M is not a multiple of the tile (8): elements past M are masked to c = 0
-__global__ void __launch_bounds__(kWave)
-k_bcd_sweep8_idx(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
-                 int32_t* __restrict__ idx_out, double* __restrict__ s_sum, int reuse_s,
-                 uint8_t* __restrict__ theta_idx) {
-    __shared__ double2 s_cand[16];                         // [k] exact phasor; 8 = the integer 0 (ENV:211, 220)
-    __shared__ OctEntry s_oct[16];
-    const int M = d.M;
-    const int lane = threadIdx.x;
-    if (lane < 16) {
-        const double r = 0.70710678118654757;              // cos(pi/4) as numpy rounds it
-        const double cr[9] = {1.0, r, 0.0, -r, -1.0, -r, 0.0, r, 0.0};
-        const double ci[9] = {0.0, r, 1.0, r, 0.0, -r, -1.0, -r, 0.0};
-        const int kc = lane < 9 ? lane : 8;
-        s_cand[lane] = make_double2(cr[kc], ci[kc]);
-        // octant code: bit0 = ax (|qi| <= t |qr|), bit1 = ay2 (|qr| <= t |qi|), bit2 = sign bit of qr, bit3 = sign bit of qi.
-        // w = (qr, -qi); ax -> k in {0, 4} by the sign of qr; ay2 (and not ax) -> k in {2, 6}: 6 when qi > 0;
-        // both (q = 0) -> k = 0, the first index; neither -> the diagonal by both signs.
-        const bool ax = lane & 1, ay2 = lane & 2, sx = lane & 4, sy = lane & 8;   // sy = (qi < 0)  <=>  -qi > 0
-        int k;
-        if (ax && ay2) k = 0;
-        else if (ax) k = sx ? 4 : 0;
-        else if (ay2) k = sy ? 2 : 6;
-        else k = sy ? (sx ? 3 : 1) : (sx ? 5 : 7);
-        OctEntry en;
-        en.nr = cr[k]; en.ni = ci[k]; en.cr = (float)cr[k]; en.ci = (float)ci[k]; en.k = k; en.pad = 0;
-        s_oct[lane] = en;
-    }
-    __syncthreads();
-    const long long e0 = (long long)blockIdx.x * kWave;
-    const bool live = e0 + lane < d.E;
-    const long long e = live ? e0 + lane : d.E - 1;
-    const double2* __restrict__ cg = reinterpret_cast<const double2*>(c_col) + (long long)blockIdx.x * M * kWave + lane;
-    const int n_blk = (M + kSweepBlk - 1) / kSweepBlk;
-    const uint8_t* __restrict__ ig = theta_idx + idx8_off(blockIdx.x, n_blk, 0, lane);
-
-    struct Tile {                                          // one 8-coordinate tile in flight: c and the old indices
-        double2 c[kSweepBlk];
-        uint2 k;
-    };
-    auto fetch = [&](Tile& t, int kb) {
-        const int kbc = kb < n_blk ? kb : n_blk - 1;           // past the end: harmless re-read of the last tile
-#pragma unroll
-        for (int j = 0; j < kSweepBlk; ++j)
-            t.c[j] = cg[(long long)(PAD ? min(kbc * kSweepBlk + j, M - 1) : kbc * kSweepBlk + j) * kWave];
-        t.k = *reinterpret_cast<const uint2*>(ig + (long long)kbc * kWave * 8);
-    };
-
-    // ---- pass 1 (only when the cached sum is not current): S = sum_m cand[k_m] c_m, two chains
-    double Sr = 0.0, Si = 0.0;
-    if (reuse_s) {
-        const double2 s0 = reinterpret_cast<const double2*>(s_sum)[e];
-        Sr = s0.x; Si = s0.y;
-    } else {
-        double Tr = 0.0, Ti = 0.0;
-        Tile ta, tb;
-        auto sum_tile = [&](int kb, const Tile& cur, Tile& nxt) {
-            fetch(nxt, kb + 1);
-#pragma unroll
-            for (int j = 0; j < kSweepBlk; j += 2) {
-                const bool ok0 = !PAD || kb * kSweepBlk + j < M, ok1 = !PAD || kb * kSweepBlk + j + 1 < M;
-                const unsigned w = j < 4 ? cur.k.x : cur.k.y;
-                const double2 a = s_cand[ok0 ? (w >> (8 * (j & 3))) & 15u : 8u];
-                const double2 b2 = s_cand[ok1 ? (w >> (8 * ((j + 1) & 3))) & 15u : 8u];
-                Sr = fma(a.x, cur.c[j].x, Sr); Sr = fma(-a.y, cur.c[j].y, Sr);
-                Si = fma(a.x, cur.c[j].y, Si); Si = fma(a.y, cur.c[j].x, Si);
-                Tr = fma(b2.x, cur.c[j + 1].x, Tr); Tr = fma(-b2.y, cur.c[j + 1].y, Tr);
-                Ti = fma(b2.x, cur.c[j + 1].y, Ti); Ti = fma(b2.y, cur.c[j + 1].x, Ti);
-            }
-        };
-        fetch(ta, 0);
-        for (int kb = 0; kb < n_blk; kb += 2) {
-            sum_tile(kb, ta, tb);
-            if (kb + 1 < n_blk) sum_tile(kb + 1, tb, ta);
-        }
-        Sr += Tr; Si += Ti;
-    }
-
-    // ---- pass 2: the chain.  Tiles ping-pong between two register images (no copies); the next tile's loads
-    // are in flight during the current tile's chain.
-    long long t_chain = 0, t_epi = 0, t_all = 0;
-    if constexpr (STAMP) t_all = -(long long)__builtin_amdgcn_s_memtime();
-    float4* __restrict__ trow4 = reinterpret_cast<float4*>(theta + e * (long long)M * 2);   // this lane's theta row
-    auto chain_tile = [&](int kb, const Tile& cur, Tile& nxt, int ahead) {
-        fetch(nxt, kb + ahead);
-        if constexpr (STAMP) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            t_chain -= (long long)__builtin_amdgcn_s_memtime();
-        }
-        const double Sr0 = Sr, Si0 = Si;
-        bool flagged = false;
-        unsigned nlo = 0, nhi = 0;
-        float2 out[kSweepBlk];
-        // the old phasors depend only on the stored indices: all eight table reads are issued before the chain
-        double2 po[kSweepBlk];
-#pragma unroll
-        for (int j = 0; j < kSweepBlk; ++j) po[j] = s_cand[((j < 4 ? cur.k.x : cur.k.y) >> (8 * (j & 3))) & 15u];
-        unsigned code[kSweepBlk];
-#pragma unroll
-        for (int j = 0; j < kSweepBlk; ++j) {
-            const bool ok = !PAD || kb * kSweepBlk + j < M;  // wave-uniform; elements past M leave S alone
-            const double cx = ok ? cur.c[j].x : 0.0, cy = ok ? cur.c[j].y : 0.0;
-            double rr = fma(-po[j].x, cx, Sr), ri = fma(-po[j].x, cy, Si);
-            rr = fma(po[j].y, cy, rr);
-            ri = fma(-po[j].y, cx, ri);
-            const double qr = fma(ri, cy, rr * cx);          // q = conj(rest) * c
-            const double qi = fma(-ri, cx, rr * cy);
-            const double t = 0.41421356237309503;            // tan(pi/8)
-            const double fa = fabs(qr), fb = fabs(qi);
-            const bool ax = fb <= t * fa, ay2 = fa <= t * fb;
-            double nr, ni;
-            octant_winner(qr, qi, ax, ay2, nr, ni);          // on the chain: bit operations only
-            Sr = fma(nr, cx, rr); Si = fma(nr, cy, ri);
-            Sr = fma(-ni, cy, Sr);
-            Si = fma(ni, cx, Si);
-            flagged |= ok && (Sr == 0.0 && Si == 0.0);
-            // off the chain: the table code of the winner (index and float32 image are looked up after the tile)
-            code[j] = (ax ? 1u : 0u) | (ay2 ? 2u : 0u) | (((unsigned)__double2hiint(qr) >> 31) << 2)
-                      | (((unsigned)__double2hiint(qi) >> 31) << 3);
-        }
-#pragma unroll
-        for (int j = 0; j < kSweepBlk; ++j) {
-            const OctEntry& en = s_oct[code[j]];
-            out[j] = make_float2(en.cr, en.ci);
-            if (j < 4) nlo |= (unsigned)en.k << (8 * j);
-            else nhi |= (unsigned)en.k << (8 * (j - 4));
-        }
-        if (__any(flagged)) {
-            // "no candidate scores above 0" (new S exactly 0; ENV:211, 220) somewhere in this tile: replay it
-            // exactly, element by element, from the saved start state
-            Sr = Sr0; Si = Si0; nlo = 0; nhi = 0;
-#pragma unroll
-            for (int j = 0; j < kSweepBlk; ++j) {
-                const bool ok = !PAD || kb * kSweepBlk + j < M;
-                const unsigned w = j < 4 ? cur.k.x : cur.k.y;
-                const double2 po = s_cand[(w >> (8 * (j & 3))) & 15u];
-                const double cx = ok ? cur.c[j].x : 0.0, cy = ok ? cur.c[j].y : 0.0;
-                double rr = fma(-po.x, cx, Sr), ri = fma(-po.x, cy, Si);
-                rr = fma(po.y, cy, rr);
-                ri = fma(-po.y, cx, ri);
-                const double qr = fma(ri, cy, rr * cx), qi = fma(-ri, cx, rr * cy);
-                const double t = 0.41421356237309503;
-                const double fa = fabs(qr), fb = fabs(qi);
-                const unsigned code = (fb <= t * fa ? 1u : 0u) | (fa <= t * fb ? 2u : 0u)
-                                      | (((unsigned)__double2hiint(qr) >> 31) << 2) | (((unsigned)__double2hiint(qi) >> 31) << 3);
-                const OctEntry en = s_oct[code];
-                double nSr = fma(en.nr, cx, rr), nSi = fma(en.nr, cy, ri);
-                nSr = fma(-en.ni, cy, nSr);
-                nSi = fma(en.ni, cx, nSi);
-                const bool none = ok && nSr == 0.0 && nSi == 0.0;
-                Sr = none ? rr : nSr;
-                Si = none ? ri : nSi;
-                out[j] = none ? make_float2(0.f, 0.f) : make_float2(en.cr, en.ci);
-                const unsigned kn = none ? 8u : (unsigned)en.k;
-                if (j < 4) nlo |= kn << (8 * j);
-                else nhi |= kn << (8 * (j - 4));
-            }
-        }
-        if constexpr (STAMP) {
-            asm volatile("" ::"v"(Sr), "v"(Si), "v"(nlo), "v"(nhi));
-            const long long now = (long long)__builtin_amdgcn_s_memtime();
-            t_chain += now;
-            t_epi -= now;
-        }
-        // New theta: this lane's 8 elements are 64 contiguous bytes of its row -- four 16-byte stores, fire and
-        // forget (the generic kernel transposes through LDS to make whole lines; for stores that bought nothing
-        // and cost ~30 instructions per tile).  The indices go out as one 8-byte word per lane, 512 B per wavefront.
-        if (live) {
-            if (!PAD) {
-#pragma unroll
-                for (int j = 0; j < kSweepBlk; j += 2)
-                    trow4[(kb * kSweepBlk + j) >> 1] = make_float4(out[j].x, out[j].y, out[j + 1].x, out[j + 1].y);
-            } else {
-#pragma unroll
-                for (int j = 0; j < kSweepBlk; ++j)
-                    if (kb * kSweepBlk + j < M) reinterpret_cast<float2*>(trow4)[kb * kSweepBlk + j] = out[j];
-            }
-        }
-        *reinterpret_cast<uint2*>(theta_idx + idx8_off(blockIdx.x, n_blk, kb, lane)) = make_uint2(nlo, nhi);
-        if (!STAMP && idx_out && live) {
-#pragma unroll
-            for (int j = 0; j < kSweepBlk; ++j) {
-                const int m = kb * kSweepBlk + j;
-                const unsigned kn = ((j < 4 ? nlo : nhi) >> (8 * (j & 3))) & 15u;
-                if (m < M) idx_out[e * M + m] = kn == 8u ? -1 : (int)kn;
-            }
-        }
-        if constexpr (STAMP) t_epi += (long long)__builtin_amdgcn_s_memtime();
-    };
-    {
-        // a ring of four tile images, three tiles (24 coordinates, ~3 us of chain) ahead of the chain: one tile
-        // ahead left ~90 cycles per coordinate of exposed memory latency (s_memtime stamps, tools/sweep_stamps.py)
-        Tile t0, t1, t2, t3;
-        fetch(t0, 0); fetch(t1, 1); fetch(t2, 2);
-        for (int kb = 0; kb < n_blk; kb += 4) {
-            chain_tile(kb, t0, t3, 3);
-            if (kb + 1 < n_blk) chain_tile(kb + 1, t1, t0, 3);
-            if (kb + 2 < n_blk) chain_tile(kb + 2, t2, t1, 3);
-            if (kb + 3 < n_blk) chain_tile(kb + 3, t3, t2, 3);
-        }
-    }
-    if (live && s_sum) reinterpret_cast<double2*>(s_sum)[e] = make_double2(Sr, Si);
-    if constexpr (STAMP) {
-        t_all += (long long)__builtin_amdgcn_s_memtime();
-        if (lane == 0 && idx_out) {
-            idx_out[blockIdx.x * 4 + 0] = (int)t_chain;
-            idx_out[blockIdx.x * 4 + 1] = (int)t_epi;
-            idx_out[blockIdx.x * 4 + 2] = (int)t_all;
-            idx_out[blockIdx.x * 4 + 3] = n_blk;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// k_bcd_sweep8_pair: the indexed sweep with TWO LANES PER ENV (round 3).
+// k_bcd_sweep8_pair: the sweep for 2^b = 8 when the candidate INDEX of every element is known (theta_idx, left by
+// the previous sweep), TWO LANES PER ENV (round 3).
 //
-// k_bcd_sweep8_idx gives 32 768 envs 512 wavefronts -- half of the chip's 1 024 SIMDs have none -- and a lone
+// The generic kernel above spends ~75 vector instructions per coordinate, most of them not on the dependent chain:
+// reading theta back through an LDS transpose, re-snapping its float32 image to the exact float64 phasor, 64-bit
+// selects for the octant winner.  With the indices known the old phasor is a table lookup hoisted out of the chain
+// and theta is not read at all.  Round 2 ran that with one lane per env (k_bcd_sweep8_idx: 512 wavefronts for 32 768
+// envs -- half of the chip's 1 024 SIMDs had none -- 348 cycles per coordinate, 243 of them in the chain); a lone
 // wavefront issues one instruction per 4 (float32 / integer) or 8 (float64) cycles whatever its dependencies, so
-// the sweep time is (instructions per coordinate) x M.  Here the even lane of a pair owns the real part of the
+// the chain time is (instructions per coordinate) x M.  Here the even lane of a pair owns the real part of the
 // running sum S, the odd lane the imaginary part: each of the three complex products of a coordinate
 // (rest = S - cand_old c, w = conj(rest) c, S' = rest + cand_new c) costs a lane 2 float64 instructions instead
 // of 4, the halves meet through DPP quad permutes (lane ^ 1: plain VALU, no LDS), each lane evaluates ONE side
@@ -696,15 +447,19 @@ k_bcd_sweep8_idx(Dims d, const double* __restrict__ c_col, float* __restrict__ t
 //   S'_self      = rest_self + n_self cx - n_other cys
 // q = 0 (every candidate ties -> the first wins, ENV:210-218) and S' = 0 (no candidate scores above 0 -> the
 // integer 0, ENV:211, 220) are detected off the chain (one v_min3 on high words per coordinate) and the tile is
-// replayed exactly, as in k_bcd_sweep8_idx.  Decisions equal that kernel's wherever best and second-best
-// candidate differ by more than float64 rounding (the imaginary parts fuse their products in another order).
+// replayed exactly from its saved start state.  Decisions equal the generic kernel's wherever best and second-best
+// candidate differ by more than float64 rounding (the products are fused differently).
+// WTH = false ("theta by index", RISVEC_BCD_NO_THETA / RISVEC_STEP_THETA_BY_INDEX): the complex64 theta row is NOT
+// written -- the indices are the state, k_theta_from_index materialises theta when somebody asks for it, and the
+// fused step reads the indices.  Measured in the BASELINE configs[4] loop the sweep is bound by its memory traffic
+// (134 MB of c_col in, 67 MB of theta out, 17 MB of indices: 44 us with either sweep kernel), not by the chain.
 // ---------------------------------------------------------------------------
 struct PairOld { double p1, p2; };                          // 16 bytes
 struct PairOut { float cr, ci; int k, pad; };               // 16 bytes
 
 __device__ __forceinline__ int dpp_x1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); }
 
-template <bool PAD, bool STAMP = false>
+template <bool PAD, bool WTH = true, bool STAMP = false>
 __global__ void __launch_bounds__(kWave)
 k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
                   int32_t* __restrict__ idx_out, double* __restrict__ s_sum, int reuse_s,
@@ -740,7 +495,7 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
     const int sl = (blockIdx.x & 1) * HALF + ei;            // this env's lane in its 64-env slab
     const double2* __restrict__ cg = reinterpret_cast<const double2*>(c_col) + slab * M * kWave + sl;
     const int n_blk = (M + kSweepBlk - 1) / kSweepBlk;
-    uint8_t* __restrict__ ig = theta_idx + idx8_off(slab, n_blk, 0, sl);
+    uint8_t* __restrict__ ig = theta_idx + e * (long long)n_blk * 8;        // this env's row of candidate indices
     const unsigned sgn = (unsigned)hb << 31;
     const PairOld* __restrict__ told = s_old[hb];
     const PairOut* __restrict__ tout = s_out[hb];
@@ -754,7 +509,7 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < kSweepBlk; ++j)
             t.c[j] = cg[(long long)(PAD ? min(kbc * kSweepBlk + j, M - 1) : kbc * kSweepBlk + j) * kWave];
-        t.k = *reinterpret_cast<const uint2*>(ig + (long long)kbc * kWave * 8);
+        t.k = *reinterpret_cast<const uint2*>(ig + kbc * 8);
     };
     auto old_of = [&](const Tile& t, int j) -> PairOld { return told[((j < 4 ? t.k.x : t.k.y) >> (8 * (j & 3))) & 15u]; };
     auto flip = [&](double cy) { return __hiloint2double(__double2hiint(cy) ^ (int)sgn, __double2loint(cy)); };
@@ -894,16 +649,18 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
             t_epi -= now;
         }
         if (live) {
-            if (!PAD) {
-                trow4[kb * 4] = make_float4(out[0].x, out[0].y, out[1].x, out[1].y);
-                trow4[kb * 4 + 1] = make_float4(out[2].x, out[2].y, out[3].x, out[3].y);
-            } else {
+            if constexpr (WTH) {
+                if (!PAD) {
+                    trow4[kb * 4] = make_float4(out[0].x, out[0].y, out[1].x, out[1].y);
+                    trow4[kb * 4 + 1] = make_float4(out[2].x, out[2].y, out[3].x, out[3].y);
+                } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (kb * kSweepBlk + 4 * hb + s < M) trow2[kb * kSweepBlk + s] = out[s];
+                    for (int s = 0; s < 4; ++s)
+                        if (kb * kSweepBlk + 4 * hb + s < M) trow2[kb * kSweepBlk + s] = out[s];
+                }
             }
+            *reinterpret_cast<unsigned*>(ig + kb * 8 + 4 * hb) = kw;
         }
-        *reinterpret_cast<unsigned*>(ig + (long long)kb * kWave * 8 + 4 * hb) = kw;
         if (!STAMP && idx_out && live) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -946,7 +703,7 @@ hipError_t launch_colsum(const RisVecState& s, hipStream_t st) {
         if (blocks < (1LL << 31)) {
             // h_r streams larger than the Infinity Cache are read with the non-temporal hint (see launch_pipe)
             static const char* nt_env = std::getenv("RISVEC_COLSUM_NT");          // "0" / "1" force it off / on (tests, A/B)
-            const bool nt = nt_env ? nt_env[0] == '1' : (long long)s.n_envs * s.n_veh * s.n_ris * 8 > (270LL << 20);
+            const bool nt = nt_env ? nt_env[0] == '1' : (long long)s.n_envs * s.n_veh * s.n_ris * 8 > tuning().colsum_nt_from;
             const dim3 g((unsigned)blocks), b(kSlabThreads);
             if (s.n_veh <= 8) {
                 if (nt) hipLaunchKernelGGL((k_colsum_slab<8, true>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);
@@ -971,55 +728,79 @@ static hipError_t launch_sweep_nc(const RisVecState& s, int32_t* idx_out, bool r
     const unsigned grid = (unsigned)((s.n_envs + kWave - 1) / kWave);
     hipLaunchKernelGGL((k_bcd_sweep<NC>), dim3(grid), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out,
                        s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, NC == 8 ? s.theta_idx : nullptr);
+    note_kernel("k_bcd_sweep<%d>", NC);
     return hipGetLastError();
 }
 
-static bool idx_sweep_disabled() {
-    static const bool off = std::getenv("RISVEC_NO_IDX_SWEEP") != nullptr;     // A/B switch for experiments
-    return off;
+// theta[e, m] = the float32 image of candidate theta_idx[e, m] (ENV:169, 213; 8 = the integer 0): materialises the
+// complex64 tensor after sweeps that kept theta by index.  One lane per 4 elements: 4 bytes in, 32 bytes out.
+__global__ void __launch_bounds__(kBlock)
+k_theta_from_index(Dims d, const uint8_t* __restrict__ theta_idx, float* __restrict__ theta) {
+    const int MK = (d.M + 7) / 8 * 8, q = MK / 4;
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)d.E * q) return;
+    const long long e = t / q;
+    const int m0 = (int)(t - e * q) * 4;
+    const unsigned w = *reinterpret_cast<const unsigned*>(theta_idx + e * MK + m0);
+    const float r = 0.70710677f;
+    float2 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned k = (w >> (8 * j)) & 15u;
+        float c = (k & 3u) == 2u ? 0.f : ((k & 1u) ? r : 1.f);
+        float sn = (k & 3u) == 0u ? 0.f : ((k & 1u) ? r : 1.f);
+        if (k >= 3u && k <= 5u) c = -c;
+        if (k >= 5u) sn = -sn;
+        o[j] = k < 8u ? make_float2(c, sn) : make_float2(0.f, 0.f);
+    }
+    float2* __restrict__ row = reinterpret_cast<float2*>(theta) + e * d.M;
+    if (m0 + 3 < d.M && (d.M & 1) == 0) {
+        float4* r4 = reinterpret_cast<float4*>(row + m0);
+        r4[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+        r4[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (m0 + j < d.M) row[m0 + j] = o[j];
+    }
+}
+
+hipError_t launch_theta_from_index(const RisVecState& s, hipStream_t st) {
+    const long long n = (long long)s.n_envs * (theta_idx_stride(s.n_ris) / 4);
+    hipLaunchKernelGGL(k_theta_from_index, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, dims_of(s),
+                       s.theta_idx, s.theta);
+    return hipGetLastError();
 }
 
 hipError_t launch_bcd(const RisVecState& s, const RisVecParams&, int32_t* idx_out, bool reuse_colsum,
-                      bool reuse_s, bool reuse_idx, hipStream_t st) {
+                      bool reuse_s, bool reuse_idx, bool write_theta, hipStream_t st) {
     if (!reuse_colsum) {
         const hipError_t err = launch_colsum(s, st);
         if (err != hipSuccess) return err;
     }
-    if (s.control_bit == 3 && reuse_idx && s.theta_idx && !idx_sweep_disabled()) {
-        const unsigned grid = (unsigned)((s.n_envs + kWave - 1) / kWave);
+    static const bool no_idx = std::getenv("RISVEC_NO_IDX_SWEEP") != nullptr;     // A/B switch: always the generic sweep
+    if (s.control_bit == 3 && reuse_idx && s.theta_idx && (!no_idx || !write_theta)) {
+        const unsigned gp = (unsigned)((s.n_envs + kWave / 2 - 1) / (kWave / 2));
+        const int rs = (reuse_s && s.s_sum) ? 1 : 0;
+        const bool pad = s.n_ris % kSweepBlk != 0;
 #ifdef RISVEC_DIAG
-        // diagnostic library only (make diag -> librisvec_diag.so, tools/sweep_stamps.py): the s_memtime builds of the sweeps
-        static const char* stamps = std::getenv("RISVEC_SWEEP_STAMPS");        // "pair" / "idx"
-        if (stamps && idx_out && s.n_ris % kSweepBlk == 0) {
-            if (stamps[0] == 'i')
-                hipLaunchKernelGGL((k_bcd_sweep8_idx<false, true>), dim3(grid), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta,
-                                   idx_out, s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
-            else
-                hipLaunchKernelGGL((k_bcd_sweep8_pair<false, true>), dim3((unsigned)((s.n_envs + kWave / 2 - 1) / (kWave / 2))),
-                                   dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out, s.s_sum,
-                                   (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
+        // diagnostic library only (make diag -> librisvec_diag.so, tools/sweep_stamps.py): the s_memtime build of the sweep
+        static const char* stamps = std::getenv("RISVEC_SWEEP_STAMPS");
+        if (stamps && idx_out && !pad) {
+            hipLaunchKernelGGL((k_bcd_sweep8_pair<false, true, true>), dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta,
+                               idx_out, s.s_sum, rs, s.theta_idx);
             return hipGetLastError();
         }
 #endif
-        static const bool no_pair = std::getenv("RISVEC_NO_PAIR_SWEEP") != nullptr;   // A/B switch: one lane per env
-        if (!no_pair) {
-            const unsigned gp = (unsigned)((s.n_envs + kWave / 2 - 1) / (kWave / 2));
-            if (s.n_ris % kSweepBlk)
-                hipLaunchKernelGGL(k_bcd_sweep8_pair<true>, dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out,
-                                   s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
-            else
-                hipLaunchKernelGGL(k_bcd_sweep8_pair<false>, dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out,
-                                   s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
-            return hipGetLastError();
-        }
-        if (s.n_ris % kSweepBlk)
-            hipLaunchKernelGGL(k_bcd_sweep8_idx<true>, dim3(grid), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out,
-                               s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
-        else
-            hipLaunchKernelGGL(k_bcd_sweep8_idx<false>, dim3(grid), dim3(kWave), 0, st, dims_of(s), s.c_col, s.theta, idx_out,
-                               s.s_sum, (reuse_s && s.s_sum) ? 1 : 0, s.theta_idx);
+#define RISVEC_PAIR(PAD, WTH) hipLaunchKernelGGL((k_bcd_sweep8_pair<PAD, WTH>), dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, \
+                                                 s.theta, idx_out, s.s_sum, rs, s.theta_idx)
+        if (pad) { if (write_theta) RISVEC_PAIR(true, true); else RISVEC_PAIR(true, false); }
+        else { if (write_theta) RISVEC_PAIR(false, true); else RISVEC_PAIR(false, false); }
+#undef RISVEC_PAIR
+        note_kernel("k_bcd_sweep8_pair<%s,%s>", pad ? "PAD" : "M%8=0", write_theta ? "theta written" : "theta by index");
         return hipGetLastError();
     }
+    if (!write_theta) return hipErrorNotSupported;            // theta by index needs current indices and 2^b = 8
     switch (s.control_bit) {
         case 0: return launch_sweep_nc<1>(s, idx_out, reuse_s, st);
         case 1: return launch_sweep_nc<2>(s, idx_out, reuse_s, st);
@@ -1037,8 +818,9 @@ hipError_t launch_step_fused_bcd(const RisVecState& s, const RisVecParams& p, co
                                  const int32_t* partner, const int32_t* n_groups,
                                  const int32_t* arrivals, uint64_t seed, uint32_t counter,
                                  uint32_t flags, hipStream_t st) {
+    const bool by_index = (flags & RISVEC_STEP_THETA_BY_INDEX) != 0;
     hipError_t err = launch_bcd(s, p, nullptr, (flags & RISVEC_STEP_REUSE_COLSUM) != 0,
-                                (flags & RISVEC_STEP_REUSE_SSUM) != 0, (flags & RISVEC_STEP_REUSE_IDX) != 0, st);
+                                (flags & RISVEC_STEP_REUSE_SSUM) != 0, (flags & RISVEC_STEP_REUSE_IDX) != 0, !by_index, st);
     if (err != hipSuccess) return err;
     return launch_step(s, p, action, partner, n_groups, arrivals, seed, counter,
                        flags & ~(uint32_t)(RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX), true, st);

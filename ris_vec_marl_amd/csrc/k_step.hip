@@ -217,6 +217,7 @@ static hipError_t launch_steer_vp(const RisVecState& s, const RisVecParams& p, c
     const dim3 grid((unsigned)((n_waves + waves - 1) / waves)), block(waves * kWave);
     if (wide) hipLaunchKernelGGL((k_step_steer<VP, true>), grid, block, per_wave * waves, st, dims_of(s), p, a, s.z_r);
     else hipLaunchKernelGGL((k_step_steer<VP, false>), grid, block, per_wave * waves, st, dims_of(s), p, a, s.z_r);
+    note_kernel("k_step_steer<%d,%s>", VP, wide ? "wide" : "narrow");
     return hipGetLastError();
 }
 
@@ -268,6 +269,7 @@ static hipError_t launch_step_vp(const RisVecState& s, const RisVecParams& p, co
     const Dims d = dims_of(s);
     if (!fused) {
         hipLaunchKernelGGL((k_step<VP>), dim3(grid), dim3(kBlock), 0, st, d, p, a);
+        note_kernel("k_step<%d>", VP);
         return hipGetLastError();
     }
     const bool even = (s.n_ris & 1) == 0;
@@ -276,6 +278,7 @@ static hipError_t launch_step_vp(const RisVecState& s, const RisVecParams& p, co
     if (g == GG) {                                                                                \
         if (even) hipLaunchKernelGGL((k_step_fused<VP, GG, 2>), dim3(grid), dim3(kBlock), 0, st, d, p, a); \
         else hipLaunchKernelGGL((k_step_fused<VP, GG, 1>), dim3(grid), dim3(kBlock), 0, st, d, p, a);      \
+        note_kernel("k_step_fused<%d,%d,%d>", VP, GG, even ? 2 : 1);                                \
         return hipGetLastError();                                                                 \
     }
     if constexpr (kWave / VP <= 8) { RISVEC_FUSED(8) }
@@ -289,8 +292,14 @@ static hipError_t launch_step_vp(const RisVecState& s, const RisVecParams& p, co
 hipError_t launch_step(const RisVecState& s, const RisVecParams& p, const float* action,
                        const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals,
                        uint64_t seed, uint32_t counter, uint32_t flags, bool fused, hipStream_t st) {
-    const StepArgs a = make_step_args(s, action, partner, n_groups, arrivals, seed, counter,
-                                      flags & ~(uint32_t)RISVEC_STEP_STEER);
+    StepArgs a = make_step_args(s, action, partner, n_groups, arrivals, seed, counter,
+                                flags & ~(uint32_t)(RISVEC_STEP_STEER | RISVEC_STEP_THETA_BY_INDEX));
+    if (fused && (flags & RISVEC_STEP_THETA_BY_INDEX)) {
+        // theta is kept by index: only the latency-shaped family has that form (the API checked the shape)
+        a.theta_k = s.theta_idx;
+        a.theta_k_stride = theta_idx_stride(s.n_ris);
+        return launch_step_fused_lat(s, p, a, st);
+    }
     if (fused && (flags & RISVEC_STEP_STEER)) {
         const hipError_t err = launch_step_steer(s, p, a, st);
         if (err != hipErrorNotSupported) return err;       // theta rows too long for LDS: stream h_r as usual
@@ -321,6 +330,7 @@ static hipError_t launch_step_multi_vp(const RisVecState& s, const RisVecParams&
     const long long threads = (long long)s.n_envs * VP;
     const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((k_step_multi<VP>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_steps, tj);
+    note_kernel("k_step_multi<%d>", VP);
     return hipGetLastError();
 }
 

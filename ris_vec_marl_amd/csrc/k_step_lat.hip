@@ -1,16 +1,24 @@
-// K34 for SMALL batches, and the multi-step launch.
+// K34 shaped for LATENCY: small batches, shapes without a software pipeline, streams beyond the Infinity Cache,
+// and the multi-step launch.
 //
-// The software pipeline of k_step_pipe.hip hides HBM latency by giving every wavefront several env
-// groups to stream through a shallow register ring.  With few envs there is nothing to stream: at
-// BASELINE configs[1] (4 096 envs x 8 x 36) it degenerates to 512 single-group wavefronts (2 per CU)
-// that each walk 8 load units two at a time -- a chain of four dependent memory round trips, 7.7 us
-// for 13 MB (rocprofv3, profiles/r02a_c2_kernel_stats.csv), where a bare read of the same bytes takes
-// 2-3 us.  The kernels here are shaped for latency instead:
+// The software pipeline of k_step_pipe.hip hides HBM latency by giving every wavefront several env groups to
+// stream through a shallow register ring.  With few envs there is nothing to stream: at BASELINE configs[1]
+// (4 096 envs x 8 x 36) it degenerates to 512 single-group wavefronts (2 per CU) that each walk 8 load units two at a
+// time -- a chain of four dependent memory round trips, 7.7 us for 13 MB (rocprofv3, profiles/r02a_c2_kernel_stats.csv),
+// where a bare read of the same bytes takes 2-3 us.  The kernels here are shaped for latency instead:
 //   * a wavefront owns EPWT <= 4 envs (not 64/VP), so even 4 096 envs make 2 048 wavefronts (8 per CU);
 //   * EVERY load of the wavefront -- its step() inputs, then all h_r / theta rows -- is issued before the
-//     first use: one memory round trip per wavefront, then the reduce, step() and the stores.
-// Same arithmetic in the same order as the pipelined kernel (same PipeShape, same transposing butterfly,
-// same step_core): results are bit-identical, which tests/test_entry_points_hip.py asserts.
+//     first use: one memory round trip per wavefront, then the reduce, step() and the stores;
+//   * with one or two envs per wavefront the gain-independent third of step() (step_pre) runs while the rows are
+//     in flight.
+// Same arithmetic in the same order as the pipelined kernel (same tiling, same transposing butterfly, same
+// step_pre / step_tail): results are bit-identical, which tests/test_entry_points_hip.py asserts.
+//
+// Round 3: the tiling is a FusedShape<V, G, NIT, MC> -- MC = 0 takes ANY even M with that (G, NIT) from the launch
+// dimensions, so every V in {4, 8, 16} x even M <= 256 has a member of this family (the reference's RIS-element study
+// runs M = 20 ... 120 at V = 8, plt/plt-ris.py:7, marl_train_bcd.py:421-423); and TK = "theta by index": the env's
+// phase shifts are read as the BCD sweep's candidate indices (1 byte per element, state.theta_idx) and expanded
+// through a 9-entry table in LDS instead of streaming the complex64 row the sweep would otherwise have to write.
 //
 // k_step_fused_lat<.., MULTI = true> is the T-step launch of SURVEY 7 ("launch latency"): n_steps
 // consecutive step() calls of the driver loop (marl_train_bcd.py:1304-1611 with the groups frozen, as
@@ -26,9 +34,7 @@
 
 namespace risvec {
 
-// STAMP: diagnostic build (tools/lat_stamps.py): TJ.reward is a debug buffer that receives, per wavefront, the
-// s_memrealtime (100 MHz) of: entry, all loads issued, cascade reduced (loads returned), step() done, stores drained.
-// NT: h_r / theta loads carry the non-temporal hint (streams beyond the 256 MiB Infinity Cache: see launch_step_fused_lat)
+// NT: h_r / theta loads carry the non-temporal hint (streams beyond the Infinity Cache: see launch_step_fused_lat)
 template <bool NT>
 __device__ __forceinline__ float4 lat_ld(const float4* p) {
     if constexpr (NT) {
@@ -40,16 +46,19 @@ __device__ __forceinline__ float4 lat_ld(const float4* p) {
     }
 }
 
-template <int V, int M, int EPWT, bool MULTI, bool STAMP = false, bool NT = false>
+// STAMP: diagnostic build only (RISVEC_DIAG, tools/lat_stamps.py): TJ.reward is a debug buffer that receives, per
+// wavefront, the s_memrealtime (100 MHz) of: entry, all loads issued, cascade reduced (loads returned), step() done,
+// stores drained.
+template <class S, int EPWT, bool MULTI, bool STAMP = false, bool NT = false, bool TK = false>
 __global__ void __launch_bounds__(kBlock)
 k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ) {
-    using S = PipeShape<V, M>;
-    constexpr int VP = S::VP, NP = S::NP, G = S::G, NIT = S::NIT, VPP = S::VPP;
+    constexpr int V = S::V, VP = S::VP, G = S::G, NIT = S::NIT, VPP = S::VPP;
     constexpr int PC = S::PC, CHUNKS = S::CHUNKS, K = S::K;
     constexpr int NU = EPWT * CHUNKS;                          // load units of the wavefront's envs
     constexpr bool EARLY_PRE = !MULTI && EPWT <= 2;            // step_pre in the shadow of the memory round trip
     static_assert(EPWT >= 1 && EPWT <= S::EPW, "a wavefront holds at most 64/VP envs");
     __shared__ float s_img[kBlock / kWave][kWave * 2];
+    __shared__ float2 s_ph[TK ? kBlock / kWave : 1][16];       // TK: the 8 candidate phasors + the integer 0, per wavefront
 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int gl = lane % G, gv = lane / G;
@@ -68,13 +77,27 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     // 7.27 -> 7.68 us), and the T-step launch pays for them once per T steps either way.
     if constexpr (!MULTI && EPWT <= 2) RISVEC_ARGS_IN_ONE_TRIP(RISVEC_STEP_PARAMS(P));
 
-    // step() inputs first: they are used last, and loads return in issue order
+    // step() inputs first: they are used first (step_pre) or last (four envs per wavefront), and loads return in issue order
     StepIn in = load_step_in(d, A, e_mine, v_mine, active);
 
     const float4* __restrict__ h4 = reinterpret_cast<const float4*>(A.h_r);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(A.theta);
     const float4* __restrict__ b4 = reinterpret_cast<const float4*>(A.b);
     const int e_last = d.E - 1;
+    const int NP = S::np(d);                                   // complex pairs per row: a constant for compile-time shapes
+
+    if constexpr (TK) {
+        // candidate k of the BCD sweep: exp(j 2 pi k / 8) as the float32 values the sweep stores (ENV:169, 213); 8 = 0
+        if (lane < 16) {
+            const float r = 0.70710677f;
+            const int k = lane & 7;
+            float c = (k & 3) == 2 ? 0.f : ((k & 1) ? r : 1.f);
+            float sn = (k & 3) == 0 ? 0.f : ((k & 1) ? r : 1.f);
+            if (k >= 3 && k <= 5) c = -c;
+            if (k >= 5) sn = -sn;
+            s_ph[wave][lane] = lane < 8 ? make_float2(c, sn) : make_float2(0.f, 0.f);
+        }
+    }
 
     float4 bq[NIT];
 #pragma unroll
@@ -89,7 +112,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int p = gl + it * G;
-        pcl[it] = (NP % G == 0 || p < NP) ? p : NP - 1;
+        pcl[it] = (!S::RAGGED || p < NP) ? p : NP - 1;
     }
     const unsigned row_off = (unsigned)(gv * NP);
     // Units are loaded in batches of up to 4 (all of them when the wavefront owns <= 4 envs: one memory
@@ -102,6 +125,7 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
 #pragma unroll
     for (int b0 = 0; b0 < NU; b0 += UB) {
         Unit<PC, NIT> u[UB];
+        unsigned tkw[UB][NIT];                                 // TK: the two candidate indices of each theta pair
 #pragma unroll
         for (int k = 0; k < UB; ++k) {
             const int ui = b0 + k;
@@ -109,7 +133,6 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
             int e = e0 + i;
             e = e < e_last ? e : e_last;                       // tail: re-read the last env, masked later
             const float4* __restrict__ hb = h4 + (long long)e * (V * NP);
-            const float4* __restrict__ tb = t4 + (long long)e * NP;
 #pragma unroll
             for (int pc = 0; pc < PC; ++pc) {
 #pragma unroll
@@ -118,9 +141,14 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
                 }
             }
             if (c == 0) {
+                if constexpr (TK) {
+                    const uint8_t* __restrict__ kb = A.theta_k + (long long)e * A.theta_k_stride;
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    u[k].t[it] = lat_ld<NT>(tb + pcl[it]);
+                    for (int it = 0; it < NIT; ++it) tkw[k][it] = *reinterpret_cast<const uint16_t*>(kb + 2 * pcl[it]);
+                } else {
+                    const float4* __restrict__ tb = t4 + (long long)e * NP;
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) u[k].t[it] = lat_ld<NT>(tb + pcl[it]);
                 }
             }
         }
@@ -144,8 +172,17 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
             if (c == 0) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    w0[it] = cmul(make_float2(u[k].t[it].x, u[k].t[it].y), make_float2(bq[it].x, bq[it].y));
-                    w1[it] = cmul(make_float2(u[k].t[it].z, u[k].t[it].w), make_float2(bq[it].z, bq[it].w));
+                    float2 t0, t1;
+                    if constexpr (TK) {
+                        __builtin_amdgcn_wave_barrier();       // the wavefront's own table writes -> its reads
+                        t0 = s_ph[wave][tkw[k][it] & 15u];
+                        t1 = s_ph[wave][(tkw[k][it] >> 8) & 15u];
+                    } else {
+                        t0 = make_float2(u[k].t[it].x, u[k].t[it].y);
+                        t1 = make_float2(u[k].t[it].z, u[k].t[it].w);
+                    }
+                    w0[it] = cmul(t0, make_float2(bq[it].x, bq[it].y));
+                    w1[it] = cmul(t1, make_float2(bq[it].z, bq[it].w));
                 }
             }
             float val[8];
@@ -195,142 +232,167 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     }
 }
 
-// envs per wavefront: as many as keep >= 8 wavefronts per CU in flight (measured: see DESIGN.md section 6)
-static int lat_epwt(int n_envs, int max_epw) {
-    static const int forced = [] { const char* s = std::getenv("RISVEC_LAT_EPW"); return s ? std::atoi(s) : -1; }();
-    if (forced >= 0) return forced;                            // 0 disables the latency-shaped single-step kernel
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+    const char* s = std::getenv(name);
+    return s ? std::atoi(s) : dflt;
+}
+
+// envs per wavefront: as many (<= 4) as keep >= 8 wavefronts per CU in flight (measured: DESIGN.md section 6)
+static int lat_epwt(int n_envs) {
+    static const int forced = env_int("RISVEC_LAT_EPW", -1);   // A/B switch; 0 disables the latency-shaped single-step kernel
+    if (forced >= 0) return forced;
     const long long want = 8LL * num_cus();
     int e = 4;
     while (e > 1 && (long long)n_envs / e < want) e >>= 1;
-    return e < max_epw ? e : max_epw;
+    return e;
 }
 
-template <int V, int M, int EPWT, bool MULTI>
-static hipError_t launch_lat_shape(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
-                                   const RisVecTraj& tj, hipStream_t st) {
+template <class S, int EPWT, bool MULTI, bool NT, bool TK>
+static hipError_t launch_one(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                             const RisVecTraj& tj, hipStream_t st) {
     const long long waves = ((long long)s.n_envs + EPWT - 1) / EPWT;
     const unsigned grid = (unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave));
-    hipLaunchKernelGGL((k_step_fused_lat<V, M, EPWT, MULTI>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_steps, tj);
+    hipLaunchKernelGGL((k_step_fused_lat<S, EPWT, MULTI, false, NT, TK>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a,
+                       n_steps, tj);
+    if (S::FIXED)
+        note_kernel("k_step_fused_lat<%d,%d,%d%s%s%s>", S::V, S::MC, EPWT, MULTI ? ",MULTI" : "", NT ? ",NT" : "", TK ? ",TK" : "");
+    else
+        note_kernel("k_step_fused_lat<%d,M=%d(G=%d,NIT=%d),%d%s%s%s>", S::V, s.n_ris, S::G, S::NIT, EPWT, MULTI ? ",MULTI" : "",
+                    NT ? ",NT" : "", TK ? ",TK" : "");
     return hipGetLastError();
 }
 
-template <int V, int M, bool MULTI>
-static hipError_t launch_lat_vm(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
-                                const RisVecTraj& tj, int epwt, hipStream_t st) {
+// One shape class, single step: EPWT in [EMIN, EMAX] by batch size (default cache policy), EMAX with the non-temporal
+// hint beyond the Infinity Cache; HAS_TK: the theta-by-index forms of the EMAX kernel exist.
+template <class S, int EMIN, int EMAX, bool HAS_TK>
+static hipError_t launch_single(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int epwt, bool nt,
+                                hipStream_t st) {
+    const RisVecTraj none{nullptr, nullptr, nullptr};
+    if (a.theta_k) {
+        if constexpr (HAS_TK) {
+            if (nt) return launch_one<S, EMAX, false, true, true>(s, p, a, 1, none, st);
+            return launch_one<S, EMAX, false, false, true>(s, p, a, 1, none, st);
+        } else {
+            return hipErrorNotSupported;
+        }
+    }
+    if (nt) return launch_one<S, EMAX, false, true, false>(s, p, a, 1, none, st);
+    if (epwt > EMAX) epwt = EMAX;
+    if (epwt < EMIN) epwt = EMIN;
+    if constexpr (EMIN <= 1 && EMAX >= 1) { if (epwt == 1) return launch_one<S, 1, false, false, false>(s, p, a, 1, none, st); }
+    if constexpr (EMIN <= 2 && EMAX >= 2) { if (epwt == 2) return launch_one<S, 2, false, false, false>(s, p, a, 1, none, st); }
+    if constexpr (EMIN <= 4 && EMAX >= 4) { if (epwt >= 3) return launch_one<S, 4, false, false, false>(s, p, a, 1, none, st); }
+    return hipErrorNotSupported;
+}
+
+template <class S>
+static hipError_t launch_multi_shape(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+                                     const RisVecTraj& tj, int epwt, hipStream_t st) {
     switch (epwt) {
-        case 1: return launch_lat_shape<V, M, 1, MULTI>(s, p, a, n_steps, tj, st);
-        case 2: return launch_lat_shape<V, M, 2, MULTI>(s, p, a, n_steps, tj, st);
-        case 4: return launch_lat_shape<V, M, 4, MULTI>(s, p, a, n_steps, tj, st);
+        case 1: return launch_one<S, 1, true, false, false>(s, p, a, n_steps, tj, st);
+        case 2: return launch_one<S, 2, true, false, false>(s, p, a, n_steps, tj, st);
+        case 4: return launch_one<S, 4, true, false, false>(s, p, a, n_steps, tj, st);
         case 8:
             // all 64 lanes stepping: only worth its registers where the step loop dominates (the T-step launch)
-            if constexpr (MULTI) return launch_lat_shape<V, M, 8, MULTI>(s, p, a, n_steps, tj, st);
+            if constexpr (S::EPW >= 8) return launch_one<S, 8, true, false, false>(s, p, a, n_steps, tj, st);
             return hipErrorNotSupported;
         default: return hipErrorNotSupported;
     }
 }
 
-// EPWT envs per wavefront (4; 1 at 16 x 256, where one env is already 34 KB in flight), single step, non-temporal loads
-template <int V, int M, int EPWT = 4>
-static hipError_t launch_lat_nt(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
-    const long long waves = ((long long)s.n_envs + EPWT - 1) / EPWT;
-    const unsigned grid = (unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave));
-    const RisVecTraj none{nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL((k_step_fused_lat<V, M, EPWT, false, false, true>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, 1, none);
-    return hipGetLastError();
+// compile-time shapes (the BASELINE configurations and the reference driver's default M = 40)
+using S8x64 = FusedShape<8, 32, 1, 64>;
+using S8x36 = FusedShape<8, 32, 1, 36>;
+using S8x40 = FusedShape<8, 32, 1, 40>;
+using S4x16 = FusedShape<4, 16, 1, 16>;
+using S16x64 = FusedShape<16, 32, 1, 64>;
+using S16x256 = FusedShape<16, 64, 2, 256>;
+
+// Shapes with a member of this family: V in {4, 8, 16}, even M <= 256.
+bool step_fused_lat_covers(int V, int M) {
+    return (V == 4 || V == 8 || V == 16) && (M & 1) == 0 && M >= 2 && M <= 256;
 }
 
-static hipError_t dispatch_lat_nt(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
-    const int V = s.n_veh, M = s.n_ris;
-    if (V == 8 && M == 64) return launch_lat_nt<8, 64>(s, p, a, st);
-    if (V == 8 && M == 36) return launch_lat_nt<8, 36>(s, p, a, st);
-    if (V == 8 && M == 40) return launch_lat_nt<8, 40>(s, p, a, st);
-    if (V == 4 && M == 16) return launch_lat_nt<4, 16>(s, p, a, st);
-    if (V == 16 && M == 256) return launch_lat_nt<16, 256, 1>(s, p, a, st);
-    return hipErrorNotSupported;
-}
+// Shapes whose fused step can read theta as the BCD sweep's candidate indices (RISVEC_STEP_THETA_BY_INDEX)
+bool theta_by_index_supported(int V, int M) { return (V == 8 && M == 64) || (V == 16 && M == 256); }
 
-template <bool MULTI>
-static hipError_t dispatch_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
-                               const RisVecTraj& tj, int epwt, hipStream_t st) {
-    const int V = s.n_veh, M = s.n_ris;
-    if constexpr (!MULTI) {
-        // 16 vehicles, single step (tools/gpu_v16.sh, us per step pipeline / this): 16 x 256 with one env per wavefront
-        // 2 048 envs 14.6 / 13.5, 4 096 25.3 / 23.4, 7 168 40.1 / 38.7 (and the non-temporal form beyond 330 MB per step:
-        // launch_step_fused_lat); 16 x 64: 4 096 envs 8.0 / 7.0, 8 192 14.5 / 14.5, from 16 384 the pipeline wins.
-        if (V == 16 && M == 256) return launch_lat_shape<16, 256, 1, false>(s, p, a, 1, tj, st);
-        if (V == 16 && M == 64 && s.n_envs <= 8192) {
-            if (epwt >= 4) return launch_lat_shape<16, 64, 4, false>(s, p, a, 1, tj, st);
-            if (epwt == 2) return launch_lat_shape<16, 64, 2, false>(s, p, a, 1, tj, st);
-            return launch_lat_shape<16, 64, 1, false>(s, p, a, 1, tj, st);
-        }
-    }
-    if (V == 8 && M == 64) return launch_lat_vm<8, 64, MULTI>(s, p, a, n_steps, tj, epwt, st);
-    if (V == 8 && M == 36) return launch_lat_vm<8, 36, MULTI>(s, p, a, n_steps, tj, epwt, st);
-    if (V == 8 && M == 40) return launch_lat_vm<8, 40, MULTI>(s, p, a, n_steps, tj, epwt, st);
-    if (V == 4 && M == 16) return launch_lat_vm<4, 16, MULTI>(s, p, a, n_steps, tj, epwt, st);
-    return hipErrorNotSupported;
-}
-
-// Single step, small and medium batches: taken instead of the software pipeline up to 24 576 envs.  Re-measured after
-// the ragged-row fix (tools/gpu_crossover.sh, profiles/r02t_lat_vs_pipe.txt; us per step, this kernel / pipeline):
-// 8 192 x 8 x 64  7.3 / 9.4, 12 288  11.5 / 12.5, 16 384  15.7 / 15.2, 20 480  17.9 / 18.7, 24 576  21.2 / 21.1,
-// 32 768  27.5 / 26.9;  M = 36: 8 192  5.7 / 6.5, 18 432  11.9 / 13.8, 32 768  18.0 / 18.4.  Four envs per wavefront with
-// every request up front keep up with the pipeline for as long as the batch is a few wavefronts per SIMD, and the
-// hardware dispatcher balances 4-env wavefronts better than the pipeline's fixed 2 048 wavefronts balance env groups
-// (18 432 envs = 2 304 groups = 1 152 wavefronts of two).
+// Single step.  Which kernel, in order:
+//   1. h_r + theta of one step beyond lat_nt_from (1.29 x the Infinity Cache): EMAX envs per wavefront, non-temporal
+//      loads -- many short hardware-dispatched wavefronts with every request up front are what the best pure reader
+//      looks like, and they beat the pipeline's 2 048 long-lived wavefronts by 1-4 % there (tools/gpu_latnt.sh,
+//      profiles/r02t_lat_nt_experiment.txt, us per step pipeline / this: 65 536 envs 59.3 / 58.5, 131 072 115.8 / 111.9,
+//      262 144 223.6 / 217.1; with the default cache policy it loses 7-12 % at those sizes).
+//   2. shapes with a software pipeline (8 x 64, 4 x 16: up to 24 wavefronts per CU of 4 envs = 24 576 envs on 256 CUs;
+//      16 x 64: 8 per CU = 8 192 envs): this kernel while the batch is that small (tools/gpu_crossover.sh,
+//      profiles/r02t_lat_vs_pipe.txt, us per step this / pipeline at 8 x 64: 8 192 envs 7.3 / 9.4, 12 288 11.5 / 12.5,
+//      20 480 17.9 / 18.7, 24 576 21.2 / 21.1, 32 768 27.5 / 26.9), the pipeline above.
+//   3. everything else (M = 36 / 40: profiles/r02u_lat_vs_pipe_ragged.txt; 16 x 256; the run-time-M members): here at
+//      every size.
+// RISVEC_LAT_MAX_ENVS (0: never this kernel where a pipeline exists), RISVEC_LAT_EPW, RISVEC_LAT_NT (0 never / 1 always /
+// 2 by size) and RISVEC_LAT_NT_MB override for A/Bs and the bit-identity tests.
 hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
-    const int vp = pow2_ceil(s.n_veh);
-    const int epw = kWave / vp;
-    static const long long limit = [] {                        // envs below which the latency shape wins
-        const char* e = std::getenv("RISVEC_LAT_MAX_ENVS");
-        return e ? std::atoll(e) : 24576LL;
-    }();
-    // Beyond the Infinity Cache (h_r + theta of one step > RISVEC_LAT_NT_MB = 330 MB; the pipeline switches to
-    // non-temporal loads from 270 MB) this kernel comes back with the non-temporal hint: many short hardware-dispatched
-    // wavefronts with every request up front are what the best pure reader looks like, and they beat the pipeline's
-    // 2 048 long-lived wavefronts by 1-4 % there (tools/gpu_latnt.sh, profiles/r02t_lat_nt_experiment.txt, us per step
-    // pipeline / this: 65 536 envs 59.3 / 58.5, 131 072 115.8 / 111.9, 262 144 223.6 / 217.1; with the default cache
-    // policy it loses 7-12 % at those sizes, and inside the cache (24 576 < envs <= ~57 000) the pipeline stays).
-    // BASELINE configs[4] (32 768 x 16 x 256, 1.1 GB per step, one env per wavefront): 251.5 -> 233 us per step with
-    // the BCD sweep, i.e. the fused kernel 198 -> 180 us.
-    // RISVEC_LAT_NT = 0 never / 1 always (tests) / 2 by size.
-    static const int nt_mode = [] { const char* e = std::getenv("RISVEC_LAT_NT"); return e ? std::atoi(e) : 2; }();
-    // (its own threshold: tools/gpu_nt_threshold.sh at 16 x 256, us per step default / non-temporal: 221 MB 33.4 / 35.8,
-    // 294 MB 43.9 / 47.4, 368 MB 66.2 / 59.9, 441 MB 78.5 / 71.0, 588 MB 107.4 / 96.6 -- the crossover is near 330 MB)
-    static const long long nt_from = [] {
-        const char* e = std::getenv("RISVEC_LAT_NT_MB");
-        return (e ? std::atoll(e) : 330LL) << 20;
-    }();
-    const long long stream_bytes = (long long)s.n_envs * (8LL * s.n_veh * s.n_ris + 8LL * s.n_ris);
-    if (limit > 0 && epw >= 4 && (nt_mode == 1 || (nt_mode == 2 && stream_bytes > nt_from))) {
-        const hipError_t err = dispatch_lat_nt(s, p, a, st);
-        if (err != hipErrorNotSupported) return err;
-    }
-    // M = 36 / 40 (18 / 20 float4 per row on 32 lanes): this kernel at EVERY size -- the pipeline's unit loader wastes the
-    // same lanes and gains nothing back (tools/gpu_crossover.sh, profiles/r02u_lat_vs_pipe_ragged.txt, us per step this
-    // kernel / pipeline at M = 40: 32 768 envs 19.3 / 19.6, 65 536 34.2 / 34.7, 98 304 62.5 / 65.7; M = 36: 65 536 31.6 / 32.7)
-    const bool ragged = s.n_veh == 8 && (s.n_ris == 36 || s.n_ris == 40) && limit > 0;
-    if ((long long)s.n_envs > limit && !ragged) return hipErrorNotSupported;
-    const int epwt = lat_epwt(s.n_envs, epw);
+    const int V = s.n_veh, M = s.n_ris;
+    if (!step_fused_lat_covers(V, M)) return hipErrorNotSupported;
+    static const long long forced_limit = [] { const char* e = std::getenv("RISVEC_LAT_MAX_ENVS"); return e ? std::atoll(e) : -1LL; }();
+    static const int nt_mode = env_int("RISVEC_LAT_NT", 2);
+    const long long stream_bytes = (long long)s.n_envs * (8LL * V * M + 8LL * M);
+    const bool off = forced_limit == 0;                        // the family is switched off where a pipeline exists
+    const bool nt = !off && (nt_mode == 1 || (nt_mode == 2 && stream_bytes > tuning().lat_nt_from));
+    const int epwt = lat_epwt(s.n_envs);
     if (epwt <= 0) return hipErrorNotSupported;
-    const RisVecTraj none{nullptr, nullptr, nullptr};
+    // wavefronts per CU (of 4 envs) up to which this kernel beats the shape's software pipeline
+    auto below = [&](int waves_per_cu) {
+        const long long limit = forced_limit >= 0 ? forced_limit : (long long)waves_per_cu * num_cus() * 4;
+        return (long long)s.n_envs <= limit;
+    };
 #ifdef RISVEC_DIAG
     // diagnostic library only (make diag -> librisvec_diag.so, tools/lat_stamps.py): the s_memrealtime build of the kernel
     if (const char* dbg = std::getenv("RISVEC_LAT_STAMPS_PTR")) {
-        if (s.n_veh == 8 && s.n_ris == 36 && epwt == 2) {
+        if (V == 8 && M == 36 && epwt == 2) {
             const RisVecTraj tj{reinterpret_cast<float*>(std::strtoull(dbg, nullptr, 0)), nullptr, nullptr};
             const long long waves = ((long long)s.n_envs + 1) / 2;
-            hipLaunchKernelGGL((k_step_fused_lat<8, 36, 2, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, st,
+            hipLaunchKernelGGL((k_step_fused_lat<S8x36, 2, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, st,
                                dims_of(s), p, a, 1, tj);
             return hipGetLastError();
         }
     }
 #endif
-    return dispatch_lat<false>(s, p, a, 1, none, epwt, st);
+    if (V == 8 && M == 64) {
+        if (!nt && !a.theta_k && !below(24)) return hipErrorNotSupported;
+        return launch_single<S8x64, 1, 4, true>(s, p, a, epwt, nt, st);
+    }
+    if (V == 4 && M == 16) {
+        if (!nt && !below(24)) return hipErrorNotSupported;
+        return launch_single<S4x16, 1, 4, false>(s, p, a, epwt, nt, st);
+    }
+    if (V == 16 && M == 64) {
+        // (tools/gpu_v16.sh, us per step pipeline / this: 4 096 envs 8.0 / 7.0, 8 192 14.5 / 14.5, from 16 384 the pipeline wins)
+        if (!below(8)) return hipErrorNotSupported;
+        return launch_single<S16x64, 1, 4, false>(s, p, a, epwt, false, st);
+    }
+    if (off && ((V == 8 && (M == 36 || M == 40)) || (V == 16 && M == 256)))
+        return hipErrorNotSupported;                           // bit-identity tests: force the pipeline where one exists
+    if (V == 8 && M == 36) return launch_single<S8x36, 1, 4, false>(s, p, a, epwt, nt, st);
+    if (V == 8 && M == 40) return launch_single<S8x40, 1, 4, false>(s, p, a, epwt, nt, st);
+    // 16 x 256 (one env = 34 loads per lane): one env per wavefront at every size (tools/gpu_v16.sh: 2 048 envs
+    // 14.6 -> 13.5 us, 4 096 25.3 -> 23.4; BASELINE configs[4] with the BCD sweep 251.5 -> 233 us per step)
+    if (V == 16 && M == 256) return launch_single<S16x256, 1, 1, true>(s, p, a, 1, nt, st);
+    // run-time M: the member with this (V, G, NIT)
+    const int g = fused_g(V, M), nit = fused_nit(V, M);
+#define RISVEC_RT(VV, GG, NN, EMIN, EMAX) \
+    if (V == VV && g == GG && nit == NN) return launch_single<FusedShape<VV, GG, NN, 0>, EMIN, EMAX, false>(s, p, a, epwt, nt, st);
+    RISVEC_RT(8, 8, 1, 2, 4) RISVEC_RT(8, 16, 1, 2, 4) RISVEC_RT(8, 32, 1, 2, 4) RISVEC_RT(8, 64, 1, 2, 4) RISVEC_RT(8, 64, 2, 2, 4)
+    RISVEC_RT(4, 16, 1, 2, 4) RISVEC_RT(4, 32, 1, 2, 4) RISVEC_RT(4, 64, 1, 2, 4) RISVEC_RT(4, 64, 2, 2, 4)
+    RISVEC_RT(16, 8, 1, 2, 4) RISVEC_RT(16, 16, 1, 2, 4) RISVEC_RT(16, 32, 1, 2, 4) RISVEC_RT(16, 64, 1, 1, 2) RISVEC_RT(16, 64, 2, 1, 1)
+#undef RISVEC_RT
+    return hipErrorNotSupported;
 }
 
 // n_steps consecutive fused steps in one launch; hipErrorNotSupported when the shape has no
-// compile-time kernel (the caller then issues n_steps single launches).
+// compile-time kernel (the caller then issues one fused launch + one launch of k_step_multi).
 hipError_t launch_step_fused_multi(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
                                    const RisVecTraj* traj, hipStream_t st) {
     // The step loop is instruction-issue-bound (one step() is ~400 dependent-ish vector instructions per
@@ -338,12 +400,17 @@ hipError_t launch_step_fused_multi(const RisVecState& s, const RisVecParams& p, 
     // lanes for -- as long as every SIMD still gets a wavefront (4 per CU).
     int epw = kWave / pow2_ceil(s.n_veh);
     if (epw > 8) epw = 8;
-    static const int forced = [] { const char* e = std::getenv("RISVEC_MULTI_EPW"); return e ? std::atoi(e) : 0; }();
+    static const int forced = env_int("RISVEC_MULTI_EPW", 0);
     int epwt = epw;
     while (epwt > 1 && (long long)s.n_envs / epwt < 4LL * num_cus()) epwt >>= 1;
     if (forced > 0) epwt = forced;
     const RisVecTraj tj = traj ? *traj : RisVecTraj{nullptr, nullptr, nullptr};
-    return dispatch_lat<true>(s, p, a, n_steps, tj, epwt, st);
+    const int V = s.n_veh, M = s.n_ris;
+    if (V == 8 && M == 64) return launch_multi_shape<S8x64>(s, p, a, n_steps, tj, epwt, st);
+    if (V == 8 && M == 36) return launch_multi_shape<S8x36>(s, p, a, n_steps, tj, epwt, st);
+    if (V == 8 && M == 40) return launch_multi_shape<S8x40>(s, p, a, n_steps, tj, epwt, st);
+    if (V == 4 && M == 16) return launch_multi_shape<S4x16>(s, p, a, n_steps, tj, epwt, st);
+    return hipErrorNotSupported;
 }
 
 }  // namespace risvec

@@ -26,6 +26,7 @@ struct SarlIn {
 };
 
 struct SarlCore {
+    static const char* name() { return "SarlCore"; }
     using Params = RisVecSarlParams;
     using Args = SarlArgs;
     using In = SarlIn;
@@ -66,6 +67,7 @@ struct GainArgs {
 };
 
 struct GainCore {
+    static const char* name() { return "GainCore"; }
     using Params = int;
     using Args = GainArgs;
     struct In { float pl; };
@@ -289,12 +291,12 @@ static hipError_t launch_pipe(const RisVecState& s, const typename Core::Params&
     // per wavefront, 2: per workgroup) is an experiment that lost at every size but one (214 vs 222 us at 262 144 envs).
     static const int chunked = env_int("RISVEC_PIPE_CHUNKED", 0);
     static const int nt_mode = env_int("RISVEC_PIPE_NT", 2);              // 0 never, 1 always, 2 by stream size
-    static const long long nt_from = (long long)env_int("RISVEC_PIPE_NT_MB", 270) << 20;
     const long long stream_bytes = (long long)s.n_envs * (8LL * V * M + 8LL * M);
-    const bool nt = nt_mode == 1 || (nt_mode == 2 && stream_bytes > nt_from);
+    const bool nt = nt_mode == 1 || (nt_mode == 2 && stream_bytes > tuning().pipe_nt_from);    // 1.055 x the Infinity Cache
     const int pw = chunked == 1 ? (int)per_wave : (chunked == 2 ? -(int)per_wave : 0);
     if (nt) hipLaunchKernelGGL((k_step_fused_pipe<V, M, D, Core, true>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_groups, pw);
     else hipLaunchKernelGGL((k_step_fused_pipe<V, M, D, Core, false>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a, n_groups, pw);
+    note_kernel("k_step_fused_pipe<%d,%d,%d,%s%s>", V, M, D, Core::name(), nt ? ",NT" : "");
     return hipGetLastError();
 }
 

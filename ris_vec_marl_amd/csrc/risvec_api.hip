@@ -12,6 +12,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local char g_kernel[160] = "";
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -74,7 +75,8 @@ int check_step(const char* fn, const RisVecState* s, const float* action, const 
     if (flags & RISVEC_STEP_OBS) REQ_PTR(s->obs, "state.obs");
     if (flags & RISVEC_STEP_POWER_W) REQ_PTR(s->power_w, "state.power_w");
     if (flags & ~(uint32_t)(RISVEC_STEP_METRICS | RISVEC_STEP_POWER_W | RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS |
-                            RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX | RISVEC_STEP_STEER))
+                            RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX | RISVEC_STEP_STEER |
+                            RISVEC_STEP_THETA_BY_INDEX))
         return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
     if (flags & RISVEC_STEP_STEER) {
         if (!fused) return fail(RISVEC_ERR_ARG, "%s: RISVEC_STEP_STEER needs the fused entry points", fn);
@@ -89,9 +91,20 @@ int check_step(const char* fn, const RisVecState* s, const float* action, const 
 
 }  // namespace
 
+namespace risvec {
+void note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+}  // namespace risvec
+
 extern "C" {
 
 uint32_t risvec_abi_version(void) { return RISVEC_ABI_VERSION; }
+
+const char* risvec_last_kernel(void) { return g_kernel; }
 
 const char* risvec_last_error(void) { return g_err; }
 
@@ -217,15 +230,29 @@ int risvec_bcd(const RisVecState* s, const RisVecParams* p, int32_t* idx_out, ui
     OPT_PTR(idx_out, "idx_out");
     OPT_PTR(s->s_sum, "state.s_sum");
     OPT_PTR(s->theta_idx, "state.theta_idx");
-    if (flags & ~(uint32_t)(RISVEC_BCD_REUSE_COLSUM | RISVEC_BCD_REUSE_SSUM | RISVEC_BCD_REUSE_IDX))
+    if (flags & ~(uint32_t)(RISVEC_BCD_REUSE_COLSUM | RISVEC_BCD_REUSE_SSUM | RISVEC_BCD_REUSE_IDX | RISVEC_BCD_NO_THETA))
         return fail(RISVEC_ERR_ARG, "%s: unknown flag bits 0x%x", fn, flags);
+    if ((flags & RISVEC_BCD_NO_THETA) && (!(flags & RISVEC_BCD_REUSE_IDX) || s->control_bit != 3))
+        return fail(RISVEC_ERR_ARG, "%s: RISVEC_BCD_NO_THETA needs RISVEC_BCD_REUSE_IDX and control_bit = 3", fn);
     if ((flags & RISVEC_BCD_REUSE_SSUM) && !s->s_sum)
         return fail(RISVEC_ERR_ARG, "%s: RISVEC_BCD_REUSE_SSUM needs state.s_sum", fn);
     if ((flags & RISVEC_BCD_REUSE_IDX) && !s->theta_idx)
         return fail(RISVEC_ERR_ARG, "%s: RISVEC_BCD_REUSE_IDX needs state.theta_idx", fn);
     return finish(fn, risvec::launch_bcd(*s, *p, idx_out, (flags & RISVEC_BCD_REUSE_COLSUM) != 0,
                                          (flags & RISVEC_BCD_REUSE_SSUM) != 0, (flags & RISVEC_BCD_REUSE_IDX) != 0,
-                                         (hipStream_t)stream));
+                                         (flags & RISVEC_BCD_NO_THETA) == 0, (hipStream_t)stream));
+}
+
+int risvec_theta_from_index(const RisVecState* s, risvec_stream_t stream) {
+    const char* fn = "risvec_theta_from_index";
+    if (int rc = check_common(fn, s, nullptr)) return rc;
+    REQ_PTR(s->theta, "state.theta"); REQ_PTR(s->theta_idx, "state.theta_idx");
+    if (s->control_bit != 3) return fail(RISVEC_ERR_UNSUPPORTED, "%s: candidate indices exist for control_bit = 3 only", fn);
+    return finish(fn, risvec::launch_theta_from_index(*s, (hipStream_t)stream));
+}
+
+int risvec_theta_by_index_supported(int32_t n_veh, int32_t n_ris) {
+    return risvec::theta_by_index_supported(n_veh, n_ris) ? 1 : 0;
 }
 
 int risvec_set_phase(const RisVecState* s, const float* angle, risvec_stream_t stream) {
@@ -250,6 +277,8 @@ int risvec_step(const RisVecState* s, const RisVecParams* p, const float* action
     if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     if (int rc = check_common(fn, s, p)) return rc;
     if (int rc = check_step(fn, s, action, partner, n_groups, arrivals, flags, false)) return rc;
+    if (flags & RISVEC_STEP_THETA_BY_INDEX)
+        return fail(RISVEC_ERR_ARG, "%s: RISVEC_STEP_THETA_BY_INDEX is a form of the fused entry points (this one reads no theta)", fn);
     return finish(fn, risvec::launch_step(*s, *p, action, partner, n_groups, arrivals, seed, counter, flags,
                                           false, (hipStream_t)stream));
 }
@@ -271,6 +300,12 @@ int risvec_step_fused(const RisVecState* s, const RisVecParams* p, const float* 
     if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     if (int rc = check_common(fn, s, p)) return rc;
     if (int rc = check_step(fn, s, action, partner, n_groups, arrivals, flags, true)) return rc;
+    if (flags & RISVEC_STEP_THETA_BY_INDEX) {                  // theta as the last sweep's candidate indices (no sweep here)
+        REQ_PTR(s->theta_idx, "state.theta_idx");
+        if (s->control_bit != 3 || !risvec::theta_by_index_supported(s->n_veh, s->n_ris) || (flags & RISVEC_STEP_STEER))
+            return fail(RISVEC_ERR_UNSUPPORTED, "%s: no theta-by-index form of the fused step for control_bit=%d, n_veh=%d, "
+                        "n_ris=%d%s", fn, s->control_bit, s->n_veh, s->n_ris, (flags & RISVEC_STEP_STEER) ? " with RISVEC_STEP_STEER" : "");
+    }
     return finish(fn, risvec::launch_step(*s, *p, action, partner, n_groups, arrivals, seed, counter, flags,
                                           true, (hipStream_t)stream));
 }
@@ -282,7 +317,7 @@ int risvec_step_fused_multi(const RisVecState* s, const RisVecParams* p, int32_t
     if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     if (int rc = check_common(fn, s, p)) return rc;
     if (n_steps < 1 || n_steps > (1 << 20)) return fail(RISVEC_ERR_ARG, "%s: n_steps=%d outside [1, 2^20]", fn, n_steps);
-    if (flags & (RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX | RISVEC_STEP_STEER))
+    if (flags & (RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX | RISVEC_STEP_STEER | RISVEC_STEP_THETA_BY_INDEX))
         return fail(RISVEC_ERR_ARG, "%s: the BCD / steering flags (0x%x) are not accepted by the multi-step launch", fn, flags);
     if (int rc = check_step(fn, s, actions, partner, n_groups, arrivals, flags, true)) return rc;
     if (traj) { OPT_PTR(traj->reward, "traj.reward"); OPT_PTR(traj->obs, "traj.obs"); OPT_PTR(traj->metrics, "traj.metrics"); }
@@ -324,7 +359,7 @@ int risvec_step_multi(const RisVecState* s, const RisVecParams* p, int32_t n_ste
     if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
     if (int rc = check_common(fn, s, p)) return rc;
     if (n_steps < 1 || n_steps > (1 << 20)) return fail(RISVEC_ERR_ARG, "%s: n_steps=%d outside [1, 2^20]", fn, n_steps);
-    if (flags & (RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX | RISVEC_STEP_STEER))
+    if (flags & (RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX | RISVEC_STEP_STEER | RISVEC_STEP_THETA_BY_INDEX))
         return fail(RISVEC_ERR_ARG, "%s: the BCD / steering flags (0x%x) are not accepted by the multi-step launch", fn, flags);
     if (int rc = check_step(fn, s, actions, partner, n_groups, arrivals, flags, false)) return rc;
     if (traj) { OPT_PTR(traj->reward, "traj.reward"); OPT_PTR(traj->obs, "traj.obs"); OPT_PTR(traj->metrics, "traj.metrics"); }
@@ -369,6 +404,15 @@ int risvec_step_fused_bcd(const RisVecState* s, const RisVecParams* p, const flo
     OPT_PTR(s->theta_idx, "state.theta_idx");
     if ((flags & RISVEC_STEP_REUSE_IDX) && !s->theta_idx)
         return fail(RISVEC_ERR_ARG, "%s: RISVEC_STEP_REUSE_IDX needs state.theta_idx", fn);
+    if (flags & RISVEC_STEP_THETA_BY_INDEX) {
+        if (!(flags & RISVEC_STEP_REUSE_IDX) || s->control_bit != 3)
+            return fail(RISVEC_ERR_ARG, "%s: RISVEC_STEP_THETA_BY_INDEX needs RISVEC_STEP_REUSE_IDX and control_bit = 3", fn);
+        if (!risvec::theta_by_index_supported(s->n_veh, s->n_ris))
+            return fail(RISVEC_ERR_UNSUPPORTED, "%s: no theta-by-index form of the fused step at n_veh=%d, n_ris=%d", fn,
+                        s->n_veh, s->n_ris);
+        if (flags & RISVEC_STEP_STEER)
+            return fail(RISVEC_ERR_ARG, "%s: RISVEC_STEP_THETA_BY_INDEX and RISVEC_STEP_STEER exclude each other", fn);
+    }
     return finish(fn, risvec::launch_step_fused_bcd(*s, *p, action, partner, n_groups, arrivals, seed,
                                                     counter, flags, (hipStream_t)stream));
 }

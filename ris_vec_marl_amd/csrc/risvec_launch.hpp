@@ -32,7 +32,7 @@ hipError_t launch_data_rate(const RisVecState& s, const RisVecParams& p, const f
 
 hipError_t launch_colsum(const RisVecState& s, hipStream_t st);
 hipError_t launch_bcd(const RisVecState& s, const RisVecParams& p, int32_t* idx_out, bool reuse_colsum,
-                      bool reuse_s, bool reuse_idx, hipStream_t st);
+                      bool reuse_s, bool reuse_idx, bool write_theta, hipStream_t st);
 hipError_t launch_step_fused_bcd(const RisVecState& s, const RisVecParams& p, const float* action,
                                  const int32_t* partner, const int32_t* n_groups,
                                  const int32_t* arrivals, uint64_t seed, uint32_t counter,
@@ -83,6 +83,13 @@ hipError_t launch_episode_accumulate(int E, int V, const float* metrics, const f
                                      float user_clip, double* acc, hipStream_t st);
 hipError_t launch_episode_summary(int E, int V, int n_steps, const double* acc, const float* metrics, double* per_env,
                                   double* partial, double* summary, hipStream_t st);
+
+// bytes per env row of state.theta_idx: the candidate index of every theta element, padded to whole 8-element tiles
+inline int theta_idx_stride(int n_ris) { return (n_ris + 7) / 8 * 8; }
+hipError_t launch_theta_from_index(const RisVecState& s, hipStream_t st);
+
+// risvec_last_kernel(): the launchers of the step path and the BCD sweep name the kernel they dispatched (per thread)
+void note_kernel(const char* fmt, ...);
 
 inline Dims dims_of(const RisVecState& s) {
     return Dims{s.n_envs, s.n_veh, s.n_ris, s.control_bit, (long long)s.env_offset};

@@ -4,25 +4,25 @@
 #pragma once
 
 #include <cstdlib>
+#include <cstring>
 
 #include "risvec_step.hpp"
 
 namespace risvec {
 
-template <int V, int M>
-struct PipeShape {
-    static constexpr int VP = pow2_ceil(V);
-    static_assert(V == VP, "pipelined kernels are instantiated for power-of-two V");
-    static_assert(M % 2 == 0, "pipelined kernels need an even M (16-byte loads)");
+// Tiling of one env onto a wavefront.  G lanes share one (env, vehicle) row of h_r (16-byte loads: two complex
+// elements per lane), NIT loads per lane cover the row, 64 / G rows are read per pass.  MC = the compile-time RIS
+// size, or 0: any EVEN M with ceil(M / 2 / G) == NIT, read from Dims at run time (round 3: the reference's own
+// RIS-element study runs M = 20 ... 120, plt/plt-ris.py:7).
+template <int V_, int G_, int NIT_, int MC_>
+struct FusedShape {
+    static constexpr int V = V_, VP = V_, G = G_, NIT = NIT_, MC = MC_;
+    static_assert(pow2_ceil(V_) == V_, "fused fast kernels are instantiated for power-of-two V");
+    static_assert(MC_ % 2 == 0, "fused fast kernels need an even M (16-byte loads)");
     static constexpr int EPW = kWave / VP;                     // envs per group
-    static constexpr int NP = M / 2;                           // complex pairs per row
-    static constexpr int G0 = pow2_ceil(NP) > kWave ? kWave : pow2_ceil(NP);
-    static constexpr int GMIN = (kWave / VP) < 8 ? 8 : (kWave / VP);
-    static constexpr int G = G0 < GMIN ? GMIN : G0;            // lanes per row
-    static constexpr int NIT = (NP + G - 1) / G;               // 16-B loads per lane per row
     static constexpr int VPP = kWave / G;                      // rows per pass
     static constexpr int PASSES = V / VPP;
-    static_assert(PASSES * VPP == V, "rows per pass must divide V");
+    static_assert(PASSES >= 1 && PASSES * VPP == V, "rows per pass must divide V");
     static constexpr int PC = PASSES >= 4 ? 4 : PASSES;        // rows per unit per lane-group
     static constexpr int CHUNKS = PASSES / PC;
     static_assert(CHUNKS * PC == PASSES, "PASSES must be a multiple of PC");
@@ -30,6 +30,25 @@ struct PipeShape {
     static constexpr int K = 2 * PC;                           // values reduced per unit
     static constexpr int WSTRIDE = G / K;                      // writer lanes: gl % WSTRIDE == 0
     static_assert(G >= K, "need at least K lanes per row");
+    static constexpr bool FIXED = MC_ != 0;
+    static constexpr bool RAGGED = !FIXED || ((MC_ / 2) % G_ != 0);     // some lanes lie past the end of a row
+    // complex pairs per row
+    static __device__ __forceinline__ int np(const Dims& d) { return FIXED ? MC_ / 2 : (d.M >> 1); }
+};
+
+// lanes per row / loads per lane for an even M (host and device): enough lanes to cover M / 2 pairs in one pass when
+// possible, but never more rows per pass than an env has, and never fewer than 8 lanes
+__host__ __device__ constexpr int fused_g(int V, int M) {
+    const int np = M / 2;
+    const int g0 = pow2_ceil(np) > kWave ? kWave : pow2_ceil(np);
+    const int gmin = (kWave / pow2_ceil(V)) < 8 ? 8 : (kWave / pow2_ceil(V));
+    return g0 < gmin ? gmin : g0;
+}
+__host__ __device__ constexpr int fused_nit(int V, int M) { return (M / 2 + fused_g(V, M) - 1) / fused_g(V, M); }
+
+template <int V, int M>
+struct PipeShape : FusedShape<V, fused_g(V, M), fused_nit(V, M), M> {
+    static constexpr int NP = M / 2;                           // complex pairs per row
 };
 
 template <int PC, int NIT>
@@ -44,6 +63,7 @@ struct Unit {
 // inputs it wants prefetched one group ahead, and the per-lane work.
 // ---------------------------------------------------------------------------
 struct MarlCore {
+    static const char* name() { return "MarlCore"; }
     using Params = RisVecParams;
     using Args = StepArgs;
     using In = StepIn;
@@ -66,17 +86,47 @@ struct MarlCore {
     }
 };
 
-inline int num_cus() {
-    static int n = [] {
-        int dev = 0, cus = 256;
+// ---------------------------------------------------------------------------
+// Dispatch thresholds, derived ONCE from the device (round 3; they were literals tuned on one box).
+//   cus            hipDeviceProp_t::multiProcessorCount
+//   ic_bytes       the Infinity Cache (memory-side L3) of the architecture: not in hipDeviceProp_t, so a table by
+//                  gcnArchName (gfx950 / gfx942: 256 MiB)
+//   pipe_nt_from   h_r + theta bytes of one step from which the software pipeline reads them with the non-temporal
+//                  hint = 1.055 x ic_bytes (measured crossover 263 ... 288 MiB on a 256 MiB cache: below it last
+//                  step's lines are still resident and the hint throws that away)
+//   lat_nt_from    the same for the latency-shaped kernel = 1.29 x ic_bytes (measured crossover 294 ... 368 MiB)
+// The RISVEC_* environment switches remain as overrides for same-box A/Bs and the bit-identity tests.
+// ---------------------------------------------------------------------------
+struct Tuning {
+    int cus;
+    long long ic_bytes, pipe_nt_from, lat_nt_from, colsum_nt_from;
+};
+
+inline const Tuning& tuning() {
+    static const Tuning t = [] {
+        Tuning r{256, 256LL << 20, 0, 0, 0};
+        int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) {
             hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                cus = prop.multiProcessorCount;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+                if (prop.multiProcessorCount > 0) r.cus = prop.multiProcessorCount;
+                const char* a = prop.gcnArchName;
+                if (std::strncmp(a, "gfx90a", 6) == 0) r.ic_bytes = 0;              // MI200: no memory-side cache
+                else if (std::strncmp(a, "gfx94", 5) == 0 || std::strncmp(a, "gfx95", 5) == 0) r.ic_bytes = 256LL << 20;
+            }
         }
-        return cus;
+        auto mb = [](const char* name, long long dflt) {
+            const char* e = std::getenv(name);
+            return e ? (std::atoll(e) << 20) : dflt;
+        };
+        r.pipe_nt_from = mb("RISVEC_PIPE_NT_MB", r.ic_bytes + r.ic_bytes * 55 / 1000);
+        r.lat_nt_from = mb("RISVEC_LAT_NT_MB", r.ic_bytes + r.ic_bytes * 29 / 100);
+        r.colsum_nt_from = r.ic_bytes + r.ic_bytes * 55 / 1000;
+        return r;
     }();
-    return n;
+    return t;
 }
+
+inline int num_cus() { return tuning().cus; }
 
 }  // namespace risvec

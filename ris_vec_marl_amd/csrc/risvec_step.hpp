@@ -47,6 +47,10 @@ struct StepArgs {
     uint64_t seed;
     uint32_t counter;
     uint32_t flags;
+    // theta by index (RISVEC_STEP_THETA_BY_INDEX): the BCD sweep's candidate indices, [E][theta_k_stride] bytes
+    // (state.theta_idx); nullptr = read the complex64 theta
+    const uint8_t* theta_k;
+    int theta_k_stride;
 };
 
 // ---------------------------------------------------------------------------
@@ -576,6 +580,7 @@ inline StepArgs make_step_args(const RisVecState& s, const float* action, const 
     a.rate = s.rate; a.data_t = s.data_t; a.data_p = s.data_p; a.reward = s.reward;
     a.over_power = s.over_power; a.obs = s.obs; a.metrics = s.metrics; a.power_w = s.power_w;
     a.seed = seed; a.counter = counter; a.flags = flags;
+    a.theta_k = nullptr; a.theta_k_stride = 0;
     return a;
 }
 
@@ -586,6 +591,8 @@ hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, c
 hipError_t launch_gain_pipe(const RisVecState& s, hipStream_t st);
 // latency-shaped single-group kernels for small batches and the multi-step launch (k_step_lat.hip)
 hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st);
+bool step_fused_lat_covers(int V, int M);
+bool theta_by_index_supported(int V, int M);
 hipError_t launch_step_fused_multi(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
                                    const RisVecTraj* traj, hipStream_t st);
 // n_steps consecutive steps on the CACHED gains in one launch, any shape (k_step.hip)

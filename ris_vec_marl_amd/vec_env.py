@@ -57,7 +57,7 @@ class VecEnviron(ParamAttrs):
 
     def __init__(self, down_lane, up_lane, left_lane, right_lane, width, height, n_veh, M, control_bit,
                  n_envs: int = 1, device: str = "cuda", seed: int = 0, env_offset: int = 0,
-                 params: Optional[EnvParams] = None):
+                 params: Optional[EnvParams] = None, lazy_theta: bool = False):
         object.__setattr__(self, "params", params if params is not None else EnvParams())
         self.down_lanes = list(down_lane)
         self.up_lanes = list(up_lane)
@@ -96,6 +96,11 @@ class VecEnviron(ParamAttrs):
         self._ssum_sweeps = 0          # >0: s_sum = sum theta.c of the CURRENT theta, left by that many
                                        # consecutive sweeps (0 = unknown; refreshed every 64 sweeps)
         self._idx_valid = False        # theta_idx = candidate index of every CURRENT theta element (left by a sweep)
+        # lazy_theta: between BCD sweeps keep theta BY INDEX (one byte per element, theta_idx): `step(bcd=True)` then
+        # neither writes nor reads the complex64 tensor (67 MB out + 67 MB in per step at BASELINE configs[4]); it is
+        # materialised when somebody asks for it (`tensors`, any other consumer).  Same step outputs bit for bit.
+        self.lazy_theta = bool(lazy_theta)
+        self._theta_stale = False      # tensors["theta"] lags behind theta_idx (only ever True with lazy_theta)
         self._cstate: Optional[N.RisVecState] = None
         self._cparams: Optional[N.RisVecParams] = None
         self._cparams_version = -1
@@ -145,8 +150,8 @@ class VecEnviron(ParamAttrs):
         t["c_col"] = z((E + 63) // 64, M, 64, 2, dt=torch.float64)
         t["s_sum"] = z(E, 2, dt=torch.float64)         # sum_m theta_m c_m left by the last sweep
         t["z_r"] = z(E, V, 2, dt=torch.float64)        # steering base exp(-j pi angle) per vehicle: h_r[e,v,m] = z^m
-        # candidate index of every theta element as the last BCD sweep left it: [ceil(E/64), ceil(M/8), 64, 8] bytes
-        t["theta_idx"] = z((E + 63) // 64, (M + 7) // 8, 64, 8, dt=torch.uint8)
+        # candidate index of every theta element as the last BCD sweep left it: [E, 8 ceil(M/8)] bytes
+        t["theta_idx"] = z(E, (M + 7) // 8 * 8, dt=torch.uint8)
         s = N.RisVecState()
         s.abi_version = N.ABI_VERSION
         s.struct_bytes = C.sizeof(N.RisVecState)
@@ -204,7 +209,19 @@ class VecEnviron(ParamAttrs):
     @property
     def tensors(self) -> Dict[str, torch.Tensor]:
         self._ensure_device()
+        self._sync_theta()
         return self._t
+
+    def _sync_theta(self) -> None:
+        """Materialise tensors["theta"] from the candidate indices if the last sweeps kept theta by index."""
+        if self._theta_stale:
+            N.check(N.load().risvec_theta_from_index(C.byref(self._cstate), self._stream()))
+            self._theta_stale = False
+
+    def _by_index(self, fused: bool, steer: bool) -> bool:
+        """Can this fused step read theta as candidate indices?  (lazy_theta, indices current, a shape with that form)"""
+        return (self.lazy_theta and fused and not steer and self._idx_valid and self.control_bit == 3
+                and bool(N.load().risvec_theta_by_index_supported(self.n_veh, self.M)))
 
     def __getattr__(self, name):
         t = self.__dict__.get("_t")
@@ -284,6 +301,7 @@ class VecEnviron(ParamAttrs):
         """theta was written by something other than a BCD sweep: its cached sum and candidate indices are stale."""
         self._ssum_sweeps = 0
         self._idx_valid = False
+        self._theta_stale = False      # whoever wrote theta made the tensor the truth again
 
     def _bcd_flags(self, reuse_colsum: Optional[bool], step: bool) -> int:
         reuse_c = self._colsum_valid if reuse_colsum is None else bool(reuse_colsum)
@@ -308,8 +326,12 @@ class VecEnviron(ParamAttrs):
         self._ensure_device()
         idx = torch.zeros(self.n_envs, self.M, dtype=torch.int32, device=self.device) if return_idx else None
         flags = self._bcd_flags(reuse_colsum, step=False)
+        lazy = self.lazy_theta and bool(flags & N.BCD_REUSE_IDX)
+        if lazy:
+            flags |= N.BCD_NO_THETA        # the indices are the state; theta follows on demand
         N.check(N.load().risvec_bcd(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(idx), flags, self._stream()))
         self._bcd_done(flags, step=False)
+        self._theta_stale = lazy
         return idx
 
     def update_channel_gains(self, u_los=None, z_shadow=None, small=None) -> None:
@@ -318,6 +340,7 @@ class VecEnviron(ParamAttrs):
         self._ensure_device()
         model = str(self.params.channel_model)
         if model == "free":
+            self._sync_theta()
             N.check(N.load().risvec_gain(C.byref(self._cstate), C.byref(self._p()), self._stream()))
             return
         E, V = self.n_envs, self.n_veh
@@ -396,17 +419,28 @@ class VecEnviron(ParamAttrs):
         flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0)
                  | (N.STEP_OBS if obs else 0) | (N.STEP_POLICY_ACTION if policy_action else 0)
                  | (self._bcd_flags(None, step=True) if bcd else 0) | self._steer_flag(steer, fused or bcd))
+        flags = self._theta_mode(flags, fused or bcd, bcd, steer)
         lib = N.load()
         fn = lib.risvec_step_fused_bcd if bcd else (lib.risvec_step_fused if fused else lib.risvec_step)
         N.check(fn(C.byref(self._cstate), C.byref(self._p()), _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng),
                    _dev_ptr(ar), self.seed, self._steps, flags, self._stream()))
         if bcd:
             self._bcd_done(flags, step=True)
+            self._theta_stale = bool(flags & N.STEP_THETA_BY_INDEX)
         self._steps += 1
         self._obs_stale = not obs
         t = self._t
         return (t["reward"], t["metrics"][:, 0], t["data_buf"], t["data_t"], t["data_p"], t["over_power"],
                 t["over_data"])
+
+    def _theta_mode(self, flags: int, fused: bool, bcd: bool, steer: bool) -> int:
+        """Decide how a step gets at theta: by index (flag added) where lazy_theta allows, else make sure the complex64
+        tensor is current for the kernels that read it."""
+        if self._by_index(fused, steer) and (not bcd or bool(flags & N.STEP_REUSE_IDX)):
+            return flags | N.STEP_THETA_BY_INDEX
+        if fused:
+            self._sync_theta()
+        return flags
 
     def step_many(self, actions, partner, n_groups, arrivals=None, metrics: bool = True, power_w: bool = False,
                   obs: bool = True, policy_action: bool = False, record: Sequence[str] = ("reward", "obs", "metrics"),
@@ -424,6 +458,8 @@ class VecEnviron(ParamAttrs):
         fused=False)` calls, the reference driver's own cadence (gains only every 100 steps), any shape, h_r / theta
         not read at all."""
         self._ensure_device()
+        if fused:
+            self._sync_theta()
         E, V = self.n_envs, self.n_veh
         a = torch.as_tensor(actions)
         if a.dim() != 4 or tuple(a.shape[1:]) != ((E, V, 2) if policy_action else (E, 2, V)):
@@ -482,6 +518,8 @@ class VecEnviron(ParamAttrs):
         pa, pp, pn, par, ptj = _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng), _dev_ptr(ar), C.byref(tj)
 
         def launch() -> None:
+            if fused:
+                self._sync_theta()
             rc = fn(cs, C.byref(self._p()), T, pa, pp, pn, par, seed, self._steps, flags, ptj, stream)
             if rc:
                 N.check(rc)
@@ -505,6 +543,7 @@ class VecEnviron(ParamAttrs):
         ph = self._arg(action_phase, torch.float32, (E, M), "action_phase")
         ar = self._arg(arrivals, torch.int32, (E, V), "arrivals")
         sp = (sarl_params or SarlParams()).to_c()
+        self._sync_theta()
         N.check(N.load().risvec_sarl_step(C.byref(self._cstate), C.byref(sp), _dev_ptr(a), _dev_ptr(ph),
                                           _dev_ptr(ar), self.seed, self._steps, N.STEP_OBS if obs else 0,
                                           self._stream()))
@@ -531,6 +570,7 @@ class VecEnviron(ParamAttrs):
         pa, pph, par, flags = _dev_ptr(a), _dev_ptr(ph), _dev_ptr(ar), N.STEP_OBS if obs else 0
 
         def launch() -> None:
+            self._sync_theta()
             rc = fn(cs, psp, pa, pph, par, seed, self._steps, flags, stream)
             if rc:
                 N.check(rc)
@@ -569,11 +609,14 @@ class VecEnviron(ParamAttrs):
 
         def launch() -> None:
             flags = base_flags | (self._bcd_flags(None, step=True) if bcd else 0)
+            if self.lazy_theta or self._theta_stale:
+                flags = self._theta_mode(flags, fused or bcd, bcd, steer)
             rc = fn(cs, C.byref(self._p()), pa, pp, pn, par, seed, self._steps, flags, stream)
             if rc:
                 N.check(rc)
             if bcd:
                 self._bcd_done(flags, step=True)
+                self._theta_stale = bool(flags & N.STEP_THETA_BY_INDEX)
             self._steps += 1
             self._obs_stale = not obs
 

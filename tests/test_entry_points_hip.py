@@ -478,7 +478,8 @@ def test_facade_takes_the_group_lists_the_reference_takes():
 
 
 # ---------------------------------------------------------------------------- non-temporal load variants
-@pytest.mark.parametrize("E,V,M", [(2100, 8, 64), (300, 16, 256), (1500, 8, 36)])
+@pytest.mark.parametrize("E,V,M", [(2100, 8, 64), (300, 16, 256), (1500, 8, 36), (1500, 8, 80), (700, 16, 100), (900, 4, 24),
+                                   (400, 8, 200)])
 def test_non_temporal_variants_are_bit_identical(E, V, M):
     """Above ~270 MiB per step the software pipeline (MARL / SARL / gain cores) and k_colsum_slab read h_r / theta with
     the non-temporal hint; the hint must not change a bit.  The switch is read once per process, so a child process
@@ -527,3 +528,113 @@ def test_non_temporal_variants_are_bit_identical(E, V, M):
         lat = np.load(dst)
         for k in outs[0].files:
             assert np.array_equal(outs[0][k], lat[k]), k
+
+
+# ---------------------------------------------------------------------------- run-time-M members of the fused family
+@pytest.mark.parametrize("E,V,M", [(3001, 8, 20), (3001, 8, 120), (2049, 8, 256), (4100, 4, 100), (1027, 16, 50), (515, 16, 120)])
+def test_runtime_m_kernel_forms_agree(E, V, M):
+    """A run-time-M shape takes k_step_fused_lat<V, M=.. (G, NIT), EPWT> with 1 / 2 / 4 envs per wavefront by batch size
+    (and the non-temporal form beyond the Infinity Cache): every form must produce the same bits.  RISVEC_LAT_EPW /
+    RISVEC_LAT_NT are read once per process, so child processes force each form; the kernel name each child reports
+    is asserted so that a dispatch change cannot silently untest a form."""
+    import subprocess
+    import sys
+    import tempfile
+    rng = np.random.default_rng(E + M)
+    action, partner, ng, arrivals = random_step_inputs(E, V, rng)
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from tests.test_entry_points_hip import _rollout_env, cpu\n"
+        "from ris_vec_marl_amd import _native as N\n"
+        "z = np.load(sys.argv[1])\n"
+        "env = _rollout_env(%d, %d, %d)\n"
+        "for _ in range(3):\n"
+        "    env.step(z['action'].astype(np.float32), z['partner'].astype(np.int32), z['ng'].astype(np.int32), z['arrivals'].astype(np.int32), fused=True)\n"
+        "out = {k: cpu(env.tensors[k]) for k in ('gain', 'reward', 'data_buf', 'mec_q', 'rate', 'metrics', 'obs', 'power_w')}\n"
+        "out['kernel'] = np.array(N.last_kernel())\n"
+        "np.savez(sys.argv[2], **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), E, V, M)
+    forms = [("epw1", dict(RISVEC_LAT_EPW="1")), ("epw2", dict(RISVEC_LAT_EPW="2")), ("epw4", dict(RISVEC_LAT_EPW="4")),
+             ("nt", dict(RISVEC_LAT_NT="1"))]
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), action=action, partner=partner, ng=ng, arrivals=arrivals)
+        outs, names = [], []
+        for name, extra in forms:
+            dst = os.path.join(tmp, name + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), dst], env=dict(os.environ, **extra),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(np.load(dst))
+            names.append(str(outs[-1]["kernel"]))
+        assert all(n.startswith("k_step_fused_lat<%d,M=%d" % (V, M)) for n in names), names
+        assert names[3].endswith(",NT>") and not names[1].endswith(",NT>"), names
+        assert len(set(names)) >= 3, names                     # at least three distinct members ran
+        for o in outs[1:]:
+            for k in outs[0].files:
+                if k != "kernel":
+                    assert np.array_equal(outs[0][k], o[k]), k
+
+
+# ---------------------------------------------------------------------------- theta kept by index (lazy_theta)
+@pytest.mark.parametrize("V,M,E", [(16, 256, 96), (8, 64, 300), (8, 64, 5000)])
+def test_theta_by_index_is_bit_identical(V, M, E):
+    """`lazy_theta=True`: between BCD sweeps theta lives as one candidate index per element -- `step(bcd=True)` takes the
+    sweep that does not write the complex64 tensor (RISVEC_STEP_THETA_BY_INDEX) and the fused step kernel that expands
+    the indices (k_step_fused_lat<.., TK>).  Every output of every step, and the tensor itself whenever it is asked
+    for, must equal the default mode's bit for bit -- through phase setters, plain fused steps, a gain refresh, a
+    stand-alone sweep and a checkpoint."""
+    from ris_vec_marl_amd import _native as N
+    rng = np.random.default_rng(V * M + E)
+    action, partner, ng, _ = random_step_inputs(E, V, rng)
+    a, pt, ngt = action.astype(np.float32), partner.astype(np.int32), ng.astype(np.int32)
+    envs = []
+    for lazy in (False, True):
+        env = _rollout_env(E, V, M)
+        env.lazy_theta = lazy
+        envs.append(env)
+    ref, lz = envs
+    keys = ("gain", "reward", "data_buf", "mec_q", "rate", "data_t", "data_p", "metrics", "obs", "power_w")
+
+    def same(what, theta=False):
+        for k in keys + (("theta", "theta_idx", "s_sum") if theta else ()):
+            assert np.array_equal(cpu(ref.tensors[k]), cpu(lz.tensors[k])), (what, k)
+
+    n_by_index = 0
+    for i in range(5):
+        arr = rng.poisson(1.0, (E, V)).astype(np.int32)
+        for env in envs:
+            env.step(a, pt, ngt, arr, fused=True, bcd=True)
+        if i >= 1:                                             # the first sweep (indices unknown) writes theta in both modes
+            assert lz._theta_stale and ",TK" in N.last_kernel(), N.last_kernel()
+            n_by_index += 1
+        assert not ref._theta_stale
+        same("bcd step %d" % i, theta=(i % 2 == 1))            # asking for tensors materialises theta
+    assert n_by_index == 4
+    for env in envs:                                           # a plain fused step on the swept theta: by index too
+        env.step(a, pt, ngt, None, fused=True)
+    assert ",TK" in N.last_kernel()
+    for env in envs:
+        env.step(a, pt, ngt, None, fused=True, bcd=True)
+        env.update_channel_gains()                             # a consumer of the complex64 tensor: materialises it first
+    assert not lz._theta_stale
+    same("gain refresh", theta=True)
+    for env in envs:
+        env.optimize_phase_shift()                             # stand-alone sweep: indices only in lazy mode
+    assert lz._theta_stale
+    same("stand-alone sweep", theta=True)
+    for env in envs:
+        env.Random_phase()                                     # a setter makes the tensor the truth again
+        env.step(a, pt, ngt, None, fused=True, bcd=True)       # generic sweep (indices unknown)
+        env.step(a, pt, ngt, None, fused=True, bcd=True)
+    same("after Random_phase", theta=True)
+    # bound launcher + checkpoint round trip
+    a_dev, pt_dev, ng_dev = torch.from_numpy(a).cuda(), torch.from_numpy(pt).cuda(), torch.from_numpy(ngt).cuda()
+    launches = [env.bind_step(a_dev, pt_dev, ng_dev, None, fused=True, bcd=True) for env in envs]
+    for _ in range(3):
+        for launch in launches:
+            launch()
+    assert lz._theta_stale
+    sd = lz.state_dict()
+    assert not lz._theta_stale
+    assert np.array_equal(sd["theta"].numpy(), cpu(ref.tensors["theta"]))
+    same("bound launches", theta=True)

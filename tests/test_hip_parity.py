@@ -443,7 +443,11 @@ def random_step_inputs(E, V, rng):
     return action, partner, ng, arrivals
 
 
-@pytest.mark.parametrize("V,M", [(8, 64), (8, 36), (4, 16), (16, 256), (6, 21), (3, 8), (32, 64), (64, 10)])
+# (8, 20 ... 120): the reference's own RIS-element study (plt/plt-ris.py:7 at V = 8, marl_train_bcd.py:421-423); with the
+# other even-M rows they take the run-time-M members of the latency-shaped family (round 3), asserted below
+@pytest.mark.parametrize("V,M", [(8, 64), (8, 36), (4, 16), (16, 256), (6, 21), (3, 8), (32, 64), (64, 10),
+                                 (8, 20), (8, 60), (8, 80), (8, 100), (8, 120), (8, 200), (8, 10), (8, 256),
+                                 (4, 24), (4, 100), (4, 250), (4, 40), (16, 20), (16, 14), (16, 50), (16, 120), (16, 200)])
 def test_fused_step_vs_oracle(V, M):
     """K34 (gain + step in one launch) on random state, including V not a power of two and
     odd M; oracle fed the same float32 tensors."""
@@ -463,6 +467,12 @@ def test_fused_step_vs_oracle(V, M):
     action, partner, ng, arrivals = random_step_inputs(E, V, rng)
     action = action.astype(np.float32)
     out = env.step(action, partner.astype(np.int32), ng.astype(np.int32), arrivals.astype(np.int32), fused=True)
+    from ris_vec_marl_amd import _native as N
+    kern = N.last_kernel()
+    if V in (4, 8, 16) and M % 2 == 0 and M <= 256:
+        assert kern.startswith("k_step_fused_lat<%d," % V), kern      # never the generic kernel for these shapes
+    else:
+        assert kern.startswith("k_step_fused<"), kern
     img = np.einsum("em,evm,m->ev", c128(t["theta"]), c128(t["h_r"]), c128(t["b"]))
     pl = cpu(t["pl"]).astype(np.float64)
     gain = pl * np.abs(img) ** 2

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Diagnostic: where the cycles of the indexed BCD sweep go (s_memtime builds of k_bcd_sweep8_pair / k_bcd_sweep8_idx in
-the DIAGNOSTIC library, `make -C ris_vec_marl_amd/csrc diag`): per wavefront, cycles inside the 8-coordinate chain vs
-the tile epilogue (theta / index stores).  Usage: sweep_stamps.py [E V M] [pair|idx]"""
+"""Diagnostic: where the cycles of the indexed BCD sweep go (the s_memtime build of k_bcd_sweep8_pair in the DIAGNOSTIC
+library, `make -C ris_vec_marl_amd/csrc diag`): per wavefront, cycles inside the 8-coordinate chain vs the tile
+epilogue (theta / index stores).  Usage: sweep_stamps.py [E V M]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KIND = sys.argv[4] if len(sys.argv) > 4 else "pair"
+KIND = "pair"
 os.environ["RISVEC_SWEEP_STAMPS"] = KIND
 os.environ["RISVEC_LIB"] = os.path.join(ROOT, "ris_vec_marl_amd", "csrc", "librisvec_diag.so")
 sys.path.insert(0, ROOT)
@@ -16,7 +16,7 @@ env.optimize_phase_shift()                      # generic kernel: leaves the ind
 for _ in range(3):
     idx = env.optimize_phase_shift(return_idx=True)
 torch.cuda.synchronize()
-EPW = 32 if KIND[0] == 'p' else 64          # envs per wavefront
+EPW = 32                                    # envs per wavefront (two lanes per env)
 a = idx.cpu().numpy().reshape(-1)[: 4 * ((E + EPW - 1) // EPW)].reshape(-1, 4).astype(np.float64)
 nb = a[0, 3]
 print(json.dumps(dict(kernel=KIND, E=E, V=V, M=M, waves=int(a.shape[0]), tiles=int(nb),
