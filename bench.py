@@ -295,17 +295,18 @@ class Case:
         if mode == "cached":
             env.update_channel_gains()
         self.multi = 1
+        self.last_kernel = ""
         self.gather, self.gather_every = None, gather_every
         self.gather_note = "n/a (1 GPU)"
         if world > 1 and gather_every > 0:
             # no try/except: a run that cannot build the collective must fail, not report a number without it
-            self.gather = rdist.JointObsGather(E, V, device)
+            self.gather = rdist.JointObsGather(E, V, device, n_buffers=GATHER_SLOTS)
             self.gather.start(env.tensors["obs"])
             self.gather.wait()
             self.gather_note = ("joint obs [E_local,5V] fp32 all-gather (torch.distributed backend %r%s) every %d step(s), "
-                                "side stream, staged + double-buffered, %.2f MB per rank per gather"
+                                "side stream, staged, %d slots in flight, %.2f MB per rank per gather"
                                 % (self.gather.backend, " = RCCL" if self.gather.backend == "nccl" else "",
-                                   gather_every, E * 20 * V / 1e6))
+                                   gather_every, GATHER_SLOTS, E * 20 * V / 1e6))
         elif world > 1:
             self.gather_note = "off (--gather-every 0)"
 
@@ -415,6 +416,9 @@ class Case:
         """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize on both sides; the wall
         time is the MAX over ranks.  Also the HIP-event time of the K launches on the launch stream."""
         device = self.device
+        from ris_vec_marl_amd import _native as N
+        self.launch()                                   # untimed: names the step kernel before other launchers overwrite it
+        self.last_kernel = N.last_kernel()
         for i in range(warmup):
             self.one_step(i)
         if self.gather is not None:
@@ -443,36 +447,29 @@ class Case:
         # stream they are issued on, so inter-launch gaps are included: slightly pessimistic)
         return dt, ev0.elapsed_time(ev1) / steps
 
-    def per_env_bytes(self) -> int:
+    def per_env_bytes(self) -> float:
         n = algorithmic_bytes(self.V, self.M, self.mode)
         if self.opts.steer and self.fused:      # h_r (8VM) replaced by the float64 steering bases (16V)
             n += 16 * self.V - 8 * self.V * self.M
+        T = getattr(self.opts, "multi", 0)
+        if T > 1:
+            # A T-step launch reads h_r / theta / the env's state once and writes the env's tensors once per T steps;
+            # what it moves EVERY step is the action (8V) and that step's trajectory record (reward 4V + obs 20V +
+            # metrics 64).  Its own algorithmic bytes per env-step, not SURVEY 8d's per-step figure (round 3: the legs
+            # used to divide the per-step figure by the launch time and print a fraction > 1).
+            return n / T + 32 * self.V + 64
         return n
 
     def kernel_name(self) -> str:
-        if self.opts.steer and self.fused:
-            return "k_step_steer"
-        pipe = (self.V, self.M) in ((8, 64), (8, 36), (8, 40), (4, 16), (16, 64), (16, 256))
-        lat = ((self.V, self.M) in ((8, 64), (8, 36), (8, 40), (4, 16), (16, 256))          # csrc/k_step_lat.hip
-               or ((self.V, self.M) == (16, 64) and self.E <= 8192))
-        if self.mode == "fused" and lat and self.V != 16 and getattr(self.opts, "multi", 0) > 1:
-            return "k_step_fused_lat<%d,%d,..,MULTI> (T-step launch)" % (self.V, self.M)
-        if self.mode == "cached" and getattr(self.opts, "multi", 0) > 1:
-            return "k_step_multi (T-step launch on cached gains)"
-        if self.mode == "fused" and getattr(self.opts, "multi", 0) > 1:
-            return "k_step_fused<..> once + k_step_multi (T-step launch, shape without a compile-time fused kernel)"
-        if (self.mode in ("fused", "bcd") and (lat or (self.V, self.M) == (16, 256))
-                and self.E * (8 * self.V * self.M + 8 * self.M) > (330 << 20)):
-            k = ("k_step_fused_lat<%d,%d,%d,NT> (%d env(s) per wavefront, every request up front, non-temporal loads: stream "
-                 "beyond the Infinity Cache)" % (self.V, self.M, 1 if self.V == 16 else 4, 1 if self.V == 16 else 4))
-            return k if self.mode == "fused" else "k_bcd_sweep + " + k
-        if self.mode in ("fused", "bcd") and lat and (self.E <= int(os.environ.get("RISVEC_LAT_MAX_ENVS", "24576"))
-                                                      or (self.V == 8 and self.M in (36, 40))):
-            k = "k_step_fused_lat<%d,%d,..> (latency-shaped: small and medium batches)" % (self.V, self.M)
-            return k if self.mode == "fused" else "k_bcd_sweep + " + k
-        k = "k_step_fused_pipe<%d,%d,..>" % (self.V, self.M) if pipe else "k_step_fused<..>"
-        return {"fused": k.replace("..>", "..,MarlCore>") if pipe else k, "cached": "k_step",
-                "bcd": "k_bcd_sweep + " + k, "sarl": "k_set_phase + " + k.replace("..>", "..,SarlCore>")}[self.mode]
+        """The kernel(s) the last launch dispatched, as the library itself reports them (risvec_last_kernel): which member
+        of the fused-step family a shape / batch size takes is a dispatch decision inside librisvec.so."""
+        from ris_vec_marl_amd import _native as N
+        k = self.last_kernel or N.last_kernel()
+        if self.mode == "bcd":
+            return ("k_bcd_sweep8_pair (two lanes per env, %s) + " % ("theta by index" if self.env.lazy_theta else "theta written")) + k
+        if self.mode == "sarl":
+            return "k_set_phase + " + k
+        return k
 
     def close(self):
         self.env = self.launch = self.group = self.store = self.marshal = self.grouper = self.meter = self.keep = None
@@ -488,27 +485,35 @@ class _Opts:
             setattr(self, k, v)
 
 
-def run_leg(name, E, V, M, mode, device, rank, world, steps, warmup, gather_every=0, multi=0, yardstick=False):
+def run_leg(name, E, V, M, mode, device, rank, world, steps, warmup, gather_every=0, multi=0, yardstick=True):
     """A secondary workload measured in the same process with the same timing protocol."""
     start = rank * E
-    case = Case(E, V, M, mode, device, rank, world, start, _Opts(multi=multi), gather_every)
+    case = (StubCase if STUB else Case)(E, V, M, mode, device, rank, world, start, _Opts(multi=multi), gather_every)
     dt, kernel_ms = case.run(steps, warmup, world)
     per_env = case.per_env_bytes()
-    out = {"launch": ("one launch per step" if multi <= 1 else "T-step launch (risvec_step_fused_multi), T = %d: gains once per "
-                      "launch, queues in registers, every step's reward / obs / metrics recorded; the h_r read is "
-                      "amortised over T steps, so roofline_frac (per-step algorithmic bytes of SURVEY 8d) can exceed what "
-                      "HBM alone could deliver" % multi),
+    out = {"launch": ("one launch per step" if multi <= 1 else "T-step launch (risvec_step_fused_multi / risvec_step_multi), T = %d: "
+                      "gains once per launch, queues in registers, every step's reward / obs / metrics recorded" % multi),
+           "launch_amortised": multi > 1,
            "workload": "%s: %d envs/GPU x %d vehicles x %d RIS elements, %s" % (workload_name(E, V, M, mode, world), E, V, M, mode),
            "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "env_steps_per_s": E * world * steps / dt,
            "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_env_step": per_env,
+           "algorithmic_bytes_note": ("SURVEY 8d per-step figure" if multi <= 1 else
+                                      "this launch's own bytes: (SURVEY 8d per-step figure) / T + 8V action + 24V + 64 record per step"),
            "roofline_frac": per_env * E / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "roofline_frac_wall": per_env * E / (dt / steps) / 1e9 / HBM_PEAK_GBS,
            "kernel": case.kernel_name(), "allgather": case.gather_note}
     if mode == "bcd":
         out["bcd_candidate_evals_per_s"] = E * world * steps / dt * M * 8
+        out["theta"] = ("kept as the sweep's candidate indices between sweeps (VecEnviron.lazy_theta): the sweep does not write "
+                        "the complex64 tensor and the fused step expands the indices; materialised on access"
+                        if case.env.lazy_theta else "complex64 tensor written by every sweep")
+    if STUB:
+        out["gather_ok"] = case.gather_ok
+        out["env_steps_per_s"] = None
     case.close()
-    if yardstick and rank == 0:
-        y = yardstick_read((8 * V * M + 8 * M) * E, device)
+    if yardstick and rank == 0 and world == 1 and not STUB:
+        # the best pure float4 reader of THE SAME NUMBER OF BYTES on this device, in this process
+        y = yardstick_read(int(per_env * E), device)
         if y:
             out["yardstick"] = y
             out["frac_of_yardstick"] = per_env * E / (kernel_ms * 1e-3) / 1e9 / y["GBps"]
@@ -537,39 +542,57 @@ def launch_ranks(args, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def stub_main(args, rank, world) -> None:
-    """Launcher / collective self-test on CPU (tests/test_dist_gloo.py): the rank processes, the rendezvous, the
-    sharding, the gather and the max-over-ranks timing of the real path with a no-op in place of the HIP step.
-    Its JSON line is labelled as such and carries no throughput."""
-    from ris_vec_marl_amd import dist as rdist
-    E, V = args.envs_per_gpu, args.veh
-    start, count = rdist.shard_range(E * world, rank, world)
-    assert count == E
-    obs = torch.full((E, V, 5), float(rank), dtype=torch.float32)
-    gather = rdist.JointObsGather(E, V, "cpu") if world > 1 and args.gather_every > 0 else None
-    joint = None
-    for i in range(args.warmup + args.steps):
-        obs.add_(1.0)
-        if gather is not None and i % args.gather_every == 0:
-            joint = gather.start(obs)
-    if gather is not None:
-        gather.wait()
-    dt = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
-    ok = True
-    if joint is not None:           # rank r's block holds r + (index of the last gathered step + 1)
-        last = ((args.warmup + args.steps - 1) // args.gather_every) * args.gather_every + 1
-        want = torch.arange(world, dtype=torch.float32).repeat_interleave(E) + last
-        ok = bool(torch.equal(joint[:, 0], want))
-    if rank == 0:
-        print(json.dumps({"metric": "launcher self-test (no GPU work)", "value": None, "unit": "env-steps/s", "stub": True,
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "max_over_ranks_s": float(dt.item()),
-                          "data": "stub", "gather_ok": ok, "env_offset_rank0": start,
-                          "backend": torch.distributed.get_backend() if world > 1 else "none"}))
-    if not ok:
-        raise SystemExit(3)
+STUB = False     # --stub: CPU self-test of the launcher / collective path (set in main)
+
+
+class StubCase:
+    """CPU stand-in for `Case` (--stub; tests/test_dist_gloo.py): the SAME main() -- rank processes, rendezvous, sharding,
+    gather cadence and slots, barriers, max-over-ranks timing, the secondary legs and the JSON schema of the real run --
+    with a no-op in place of the HIP step.  Its line is labelled `"stub": true` and carries no throughput."""
+
+    def __init__(self, E, V, M, mode, device, rank, world, start, opts, gather_every):
+        from ris_vec_marl_amd import dist as rdist
+        self.E, self.V, self.M, self.mode, self.rank, self.world, self.start = E, V, M, mode, rank, world, start
+        self.opts = opts
+        self.fused, self.bcd, self.full = mode != "cached", mode == "bcd", True
+        self.obs = torch.full((E, V, 5), float(rank), dtype=torch.float32)
+        self.gather_every = gather_every
+        self.gather = rdist.JointObsGather(E, V, "cpu", n_buffers=GATHER_SLOTS) if world > 1 and gather_every > 0 else None
+        self.gather_note = ("off" if self.gather is None else
+                            "joint obs all-gather (torch.distributed backend %r) every %d step(s), %d slots"
+                            % (self.gather.backend, gather_every, GATHER_SLOTS))
+        self.gather_ok = True
+        self.env = type("E", (), {"lazy_theta": False})()
+
+    def run(self, steps, warmup, world):
+        joint, n = None, 0
+        for i in range(warmup + steps):
+            self.obs.add_(1.0)
+            n += 1
+            if self.gather is not None and i % self.gather_every == 0:
+                joint, stamp = self.gather.start(self.obs), n
+        if self.gather is not None:
+            self.gather.wait()
+        dt = torch.tensor([0.001 * (self.rank + 1)], dtype=torch.float64)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+        if joint is not None:                     # rank r's block holds r + (number of steps before the last gather)
+            want = torch.arange(world, dtype=torch.float32).repeat_interleave(self.E) + stamp
+            self.gather_ok = bool(torch.equal(joint[:, 0], want))
+        return float(dt.item()), float(dt.item()) / max(1, steps) * 1e3
+
+    def per_env_bytes(self):
+        return algorithmic_bytes(self.V, self.M, self.mode)
+
+    def kernel_name(self):
+        return "stub (no GPU work)"
+
+    def close(self):
+        self.gather = None
+
+
+GATHER_SLOTS = 4        # (stage, output) slots of the joint-observation gather: up to 4 gathers in flight
 
 
 def main() -> None:
@@ -652,20 +675,23 @@ def main() -> None:
         cpu = cpu_baseline(args.veh, args.ris)
 
     from ris_vec_marl_amd import dist as rdist
-    if args.stub:
+    global STUB
+    STUB = bool(args.stub)
+    if STUB:
         os.environ.setdefault("RISVEC_DIST_BACKEND", "gloo")
-        rdist.init_from_env(backend="gloo")
-        stub_main(args, rank, world)
-        return
-    rank, world, local = rdist.init_from_env()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+        rank, world, local = rdist.init_from_env(backend="gloo")
+        device = torch.device("cpu")
+    else:
+        rank, world, local = rdist.init_from_env()
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
     E, V, M = args.envs_per_gpu, args.veh, args.ris
     start, _ = rdist.shard_range(E * world, rank, world)
-    case = Case(E, V, M, args.mode, device, rank, world, start, args, args.gather_every)
+    case = (StubCase if STUB else Case)(E, V, M, args.mode, device, rank, world, start, args, args.gather_every)
     dt, kernel_ms = case.run(args.steps, args.warmup, world)
+    gather_ok = getattr(case, "gather_ok", True)
     fused, bcd, full = case.fused, case.bcd, case.full
     per_env = case.per_env_bytes()
     gather_note = case.gather_note
@@ -677,16 +703,17 @@ def main() -> None:
     default_shape = (E, V, M, args.mode) == CONFIGS["c3"][:4] and not (args.noma or args.lean or args.steer or args.meter)
     if default_shape and not args.no_legs:
         if world == 1:
-            legs["hbm_only"] = run_leg("hbm_only", 262144, 8, 64, "fused", device, rank, world, 200, 30, yardstick=True)
+            legs["hbm_only"] = run_leg("hbm_only", 262144, 8, 64, "fused", device, rank, world, 200, 30)
             legs["c2"] = run_leg("c2", *CONFIGS["c2"][:4], device, rank, world, 2000, 200)
             legs["c2_multi_step"] = run_leg("c2", *CONFIGS["c2"][:4], device, rank, world, 3200, 320, multi=32)
             legs["c4_shard"] = run_leg("c4_shard", *CONFIGS["c4"][:4], device, rank, world, 2000, 200)
             legs["c5"] = run_leg("c5", *CONFIGS["c5"][:4], device, rank, world, 200, 30)
             legs["cached"] = run_leg("cached", 32768, 8, 64, "cached", device, rank, world, 2000, 200)
         else:
-            legs["c4_gather_every_1"] = run_leg("c4", *CONFIGS["c4"][:4], device, rank, world, 2000, 200, gather_every=1)
-            legs["c4_gather_every_32"] = run_leg("c4", *CONFIGS["c4"][:4], device, rank, world, 2000, 200, gather_every=32)
-            legs["c4_no_gather"] = run_leg("c4", *CONFIGS["c4"][:4], device, rank, world, 2000, 200, gather_every=0)
+            n_leg, w_leg = (40, 4) if STUB else (2000, 200)
+            legs["c4_gather_every_1"] = run_leg("c4", *CONFIGS["c4"][:4], device, rank, world, n_leg, w_leg, gather_every=1)
+            legs["c4_gather_every_32"] = run_leg("c4", *CONFIGS["c4"][:4], device, rank, world, n_leg, w_leg, gather_every=32)
+            legs["c4_no_gather"] = run_leg("c4", *CONFIGS["c4"][:4], device, rank, world, n_leg, w_leg, gather_every=0)
 
     if rank != 0:
         return
@@ -694,11 +721,11 @@ def main() -> None:
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     achieved_wall = bytes_per_launch / (dt / args.steps) / 1e9
     traffic, traffic_src = (None, None)
-    if (E, V, M, args.mode) == (32768, 8, 64, "fused") and full and not args.steer:
+    if (E, V, M, args.mode) == (32768, 8, 64, "fused") and full and not args.steer and not STUB:
         traffic, traffic_src = measured_traffic("k_step_fused")
     yard = None
-    if world == 1 and fused and not args.steer:
-        yard = yardstick_read((8 * V * M + 8 * M) * E, device)
+    if world == 1 and fused and not args.steer and not STUB:
+        yard = yardstick_read(int(per_env * E), device)
     work = {"fused": "RIS cascaded gains + step()", "cached": "step() on cached gains",
             "bcd": "BCD sweep + gains + step()", "sarl": "SARL get_next_phase + gains + step()"}[args.mode]
     out = {
@@ -746,8 +773,16 @@ def main() -> None:
     }
     if bcd:
         out["config"]["bcd_candidate_evals_per_s"] = E * world * args.steps / dt * M * 8
+    out["config"]["allgather_backend"] = torch.distributed.get_backend() if world > 1 else "none"
     out["cpu_baseline"] = cpu
+    if STUB:      # a self-test line can never be mistaken for a measurement
+        out.update(metric="launcher self-test (no GPU work)", value=None, stub=True, data="stub", max_over_ranks_s=dt,
+                   gather_ok=bool(gather_ok and all(leg.get("gather_ok", True) for leg in legs.values())),
+                   env_offset_rank0=start, backend=out["config"]["allgather_backend"])
+        out["config"]["agent_steps_per_s"] = None
     print(json.dumps(out))
+    if STUB and not out["gather_ok"]:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

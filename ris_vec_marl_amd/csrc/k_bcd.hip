@@ -459,7 +459,7 @@ struct PairOut { float cr, ci; int k, pad; };               // 16 bytes
 
 __device__ __forceinline__ int dpp_x1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); }
 
-template <bool PAD, bool WTH = true, bool STAMP = false>
+template <bool PAD, bool WTH = true, bool STAMP = false, int RING = 4>
 __global__ void __launch_bounds__(kWave)
 k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
                   int32_t* __restrict__ idx_out, double* __restrict__ s_sum, int reuse_s,
@@ -672,13 +672,15 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
         if constexpr (STAMP) t_epi += (long long)__builtin_amdgcn_s_memtime();
     };
     {
-        Tile t0, t1, t2, t3;                               // a ring of four tile images, three tiles ahead of the chain
-        fetch(t0, 0); fetch(t1, 1); fetch(t2, 2);
-        for (int kb = 0; kb < n_blk; kb += 4) {
-            chain_tile(kb, t0, t3, 3);
-            if (kb + 1 < n_blk) chain_tile(kb + 1, t1, t0, 3);
-            if (kb + 2 < n_blk) chain_tile(kb + 2, t2, t1, 3);
-            if (kb + 3 < n_blk) chain_tile(kb + 3, t3, t2, 3);
+        // a ring of RING tile images, RING - 1 tiles ahead of the chain: the requests a wavefront keeps in flight
+        // (RING - 1) x 4 KiB; every slot has its own copy of the tile code, so the images never move between registers
+        Tile ring[RING];
+#pragma unroll
+        for (int r = 0; r + 1 < RING; ++r) fetch(ring[r], r);
+        for (int kb = 0; kb < n_blk; kb += RING) {
+#pragma unroll
+            for (int r = 0; r < RING; ++r)
+                if (kb + r < n_blk) chain_tile(kb + r, ring[r], ring[(r + RING - 1) % RING], RING - 1);
         }
     }
     if (live && s_sum) s_sum[e * 2 + hb] = S;
@@ -792,10 +794,13 @@ hipError_t launch_bcd(const RisVecState& s, const RisVecParams&, int32_t* idx_ou
             return hipGetLastError();
         }
 #endif
-#define RISVEC_PAIR(PAD, WTH) hipLaunchKernelGGL((k_bcd_sweep8_pair<PAD, WTH>), dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, \
-                                                 s.theta, idx_out, s.s_sum, rs, s.theta_idx)
-        if (pad) { if (write_theta) RISVEC_PAIR(true, true); else RISVEC_PAIR(true, false); }
-        else { if (write_theta) RISVEC_PAIR(false, true); else RISVEC_PAIR(false, false); }
+        static const int ring = [] { const char* e = std::getenv("RISVEC_SWEEP_RING"); return e ? std::atoi(e) : 4; }();
+#define RISVEC_PAIR(PAD, WTH, R) hipLaunchKernelGGL((k_bcd_sweep8_pair<PAD, WTH, false, R>), dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, \
+                                                    s.theta, idx_out, s.s_sum, rs, s.theta_idx)
+#define RISVEC_PAIR_R(PAD, WTH) do { if (ring == 8) RISVEC_PAIR(PAD, WTH, 8); else if (ring == 6) RISVEC_PAIR(PAD, WTH, 6); else RISVEC_PAIR(PAD, WTH, 4); } while (0)
+        if (pad) { if (write_theta) RISVEC_PAIR_R(true, true); else RISVEC_PAIR_R(true, false); }
+        else { if (write_theta) RISVEC_PAIR_R(false, true); else RISVEC_PAIR_R(false, false); }
+#undef RISVEC_PAIR_R
 #undef RISVEC_PAIR
         note_kernel("k_bcd_sweep8_pair<%s,%s>", pad ? "PAD" : "M%8=0", write_theta ? "theta written" : "theta by index");
         return hipGetLastError();

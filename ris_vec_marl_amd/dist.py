@@ -48,18 +48,23 @@ class JointObsGather:
     """All-gather of the per-rank observation block obs_local [E_local, V, 5] into the joint
     observation [E_global, 5V] (the input a replicated global critic consumes).
 
-    The env overwrites its `obs` tensor every step, so `start()` first snapshots it into a
-    private staging buffer on the caller's stream (one 20V-byte-per-env device copy), then
-    issues the RCCL all-gather from that snapshot on a side stream into one of two output
-    buffers: the collective overlaps the following env steps instead of sitting on their
-    critical path, and nothing it reads or writes is touched by them.  `wait()` makes the
-    result visible to the caller's stream.  xGMI is point-to-point, so the gather is per-link
-    bound ((N-1) x message bytes into every GPU): pick its cadence accordingly.  Equal shard
-    sizes are required (use an E divisible by the world size).
+    The env overwrites its `obs` tensor every step, so `start()` first snapshots it into a private
+    staging buffer on the caller's stream (one 20V-byte-per-env device copy), then issues the RCCL
+    all-gather from that snapshot on a side stream into an output buffer: the collective overlaps the
+    following env steps instead of sitting on their critical path, and nothing it reads or writes is
+    touched by them.  There are `n_buffers` (stage, output) SLOTS used round-robin, so up to `n_buffers`
+    gathers can be in flight: `start()` only ever waits -- on the device, not on the host -- for the gather
+    that last used the slot it is about to refill (round 2 had one staging buffer and began every `start()`
+    by waiting for the previous gather: with a gather every step the step stream stalled on the links).
+    `wait()` makes the most recent gather (and, the side stream being in order, every earlier one) visible
+    to the caller's stream; the tensor `start()` returned is valid from then until its slot is reused,
+    `n_buffers` starts later.  xGMI is point-to-point, so the gather is per-link bound ((N-1) x message
+    bytes into every GPU): pick its cadence accordingly.  Equal shard sizes are required (use an E
+    divisible by the world size).
 
-    A single process (no process group, or a group of one rank) runs the SAME staging / side-stream
-    / double-buffer sequence with the collective replaced by a device copy (a one-rank group still
-    issues the collective), so the single-GPU tests exercise the logic the multi-GPU run relies on."""
+    A single process (no process group, or a group of one rank) runs the SAME staging / side-stream /
+    slot sequence with the collective replaced by a device copy (a one-rank group still issues the
+    collective), so the single-GPU tests exercise the logic the multi-GPU run relies on."""
 
     def __init__(self, n_envs_local: int, n_veh: int, device, group=None, n_buffers: int = 2):
         self.group = group
@@ -73,47 +78,77 @@ class JointObsGather:
             raise ValueError("JointObsGather: n_buffers must be >= 1")
         self.n_envs_local = int(n_envs_local)
         self.width = 5 * int(n_veh)
-        self.stage = torch.empty(self.n_envs_local, self.width, dtype=torch.float32, device=self.device)
-        self.bufs = [torch.empty(self.world * self.n_envs_local, self.width, dtype=torch.float32, device=self.device)
-                     for _ in range(n_buffers)]
+        mk = lambda n: torch.empty(n, self.width, dtype=torch.float32, device=self.device)   # noqa: E731
+        self.stages = [mk(self.n_envs_local) for _ in range(n_buffers)]
+        self.bufs = [mk(self.world * self.n_envs_local) for _ in range(n_buffers)]
         self.i = 0
-        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self._work = None
+        on_gpu = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if on_gpu else None
+        self._done = [torch.cuda.Event() if on_gpu else None for _ in range(n_buffers)]     # side stream: slot's gather finished
+        self._busy = [False] * n_buffers            # slot has a gather whose completion nobody has ordered against yet
+        self._work = [None] * n_buffers             # host-side handles (gloo on CPU: no stream to order on)
+        self._last = None                           # slot of the most recent start()
         self.n_started = 0
+
+    @property
+    def stage(self) -> torch.Tensor:                # the staging buffer of the slot the next start() fills
+        return self.stages[self.i]
+
+    def in_flight(self) -> int:
+        """Gathers started and not yet ordered against by a `wait()` / a slot reuse."""
+        return sum(self._busy)
 
     def start(self, obs_local: torch.Tensor) -> torch.Tensor:
         """Snapshot `obs_local` and launch its gather; returns the buffer it will land in
-        (valid after `wait()`)."""
+        (valid after `wait()`, until the slot is reused `n_buffers` starts later)."""
         if obs_local.shape[0] != self.n_envs_local or obs_local.numel() != self.n_envs_local * self.width:
             raise ValueError("JointObsGather.start: obs_local must be [%d, V, 5] with 5V = %d, got %s"
                              % (self.n_envs_local, self.width, tuple(obs_local.shape)))
-        self.wait()                                   # the previous gather still reads `stage`
-        out = self.bufs[self.i]
+        k = self.i
         self.i = (self.i + 1) % len(self.bufs)
+        self._release(k)                              # only the gather that last used THIS slot still reads stage[k]
+        out, stage = self.bufs[k], self.stages[k]
         self.n_started += 1
+        self._last = k
         src = obs_local.reshape(self.n_envs_local, self.width)
-        self.stage.copy_(src, non_blocking=True)      # caller's stream: ordered after the step that wrote obs
+        stage.copy_(src, non_blocking=True)           # caller's stream: ordered after the step that wrote obs
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.stream):
-                self._issue(out)
+                if self.collective:
+                    # async_op: the communicator's own stream runs the collective; wait() here orders the SIDE stream
+                    # behind it (a device-side dependency), so the event below marks the gather's completion
+                    td.all_gather_into_tensor(out, stage, group=self.group, async_op=True).wait()
+                else:
+                    out.copy_(stage, non_blocking=True)
+                self._done[k].record(self.stream)
+        elif self.collective:
+            self._work[k] = td.all_gather_into_tensor(out, stage, group=self.group, async_op=True)
         else:
-            self._issue(out)
+            out.copy_(stage)
+        self._busy[k] = True
         return out
 
-    def _issue(self, out: torch.Tensor) -> None:
-        if self.collective:
-            self._work = td.all_gather_into_tensor(out, self.stage, group=self.group, async_op=True)
-        else:
-            out.copy_(self.stage, non_blocking=True)
+    def _release(self, k: int) -> None:
+        """Order the caller's stream (or the host, without streams) behind slot k's gather."""
+        if not self._busy[k]:
+            return
+        if self.stream is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._done[k])
+        elif self._work[k] is not None:
+            self._work[k].wait()
+            self._work[k] = None
+        self._busy[k] = False
 
     def wait(self) -> None:
-        """Make the last started gather visible to the current stream."""
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
+        """Make every gather started so far visible to the current stream."""
         if self.stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            if self._last is not None and self._busy[self._last]:
+                torch.cuda.current_stream(self.device).wait_event(self._done[self._last])   # in-order side stream: covers all
+            self._busy = [False] * len(self._busy)
+        else:
+            for k in range(len(self._busy)):
+                self._release(k)
 
 
 def gather_joint_obs(obs_local: torch.Tensor, group=None) -> torch.Tensor:

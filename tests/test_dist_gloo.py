@@ -122,6 +122,29 @@ def test_bench_launcher_spawns_the_ranks_it_was_asked_for():
     assert abs(d["max_over_ranks_s"] - 0.002) < 1e-12          # MAX over ranks (rank 1 reported 2 ms)
 
 
+def test_bench_scale_command_with_eight_ranks():
+    """The command the driver's SCALE step issues -- `python bench.py --gpus 8` with the default workload -- end to end on
+    CPU (gloo, the HIP step stubbed out): 8 rank processes, 32 768 envs per rank, the three BASELINE configs[3] legs
+    (8 192 envs per rank with the all-gather every step / every 32 steps / off), every gather's contents checked on
+    rank 0, and the JSON schema of the real line (`n_gpus`, `legs`, the backend named)."""
+    import json
+    r = _bench("--gpus", "8", "--stub", "--steps", "6", "--warmup", "2", timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["stub"] is True and d["value"] is None and d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["envs_per_gpu"] == 32768 and d["config"]["allgather_backend"] == "gloo"
+    assert set(d["legs"]) == {"c4_gather_every_1", "c4_gather_every_32", "c4_no_gather"}
+    for name, leg in d["legs"].items():
+        assert "BASELINE configs[3]" in leg["workload"] and leg["gather_ok"] is True, name
+        assert leg["env_steps_per_s"] is None
+    assert "every 1 step" in d["legs"]["c4_gather_every_1"]["allgather"] and d["legs"]["c4_no_gather"]["allgather"] == "off"
+    assert d["gather_ok"] is True and abs(d["max_over_ranks_s"] - 0.008) < 1e-12      # MAX over 8 ranks
+    for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert key in d, key
+
+
 def test_bench_never_silently_runs_fewer_ranks():
     """No device in this container: `--gpus 2` must exit non-zero (not fall back to one rank), and a WORLD_SIZE that
     differs from --gpus is refused as well."""

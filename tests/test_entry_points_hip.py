@@ -166,6 +166,26 @@ def _check_gather(g, env, a, pt, ngt):
     assert g.n_started == 4 and g.i == 0                 # two buffers, used alternately
 
 
+def _check_gathers_in_flight(g, env, a, pt, ngt, k=3):
+    """k gathers started back to back, each after another env step, BEFORE the first wait: every returned buffer must
+    hold the observation at ITS start(); then one more round through the same slots (slot reuse orders itself)."""
+    t = env.tensors
+    E, V = env.n_envs, env.n_veh
+    for rnd in range(2):
+        wants, outs = [], []
+        for _ in range(k):
+            env.step(a, pt, ngt, None, fused=True)
+            wants.append(t["obs"].reshape(E, 5 * V).clone())
+            outs.append(g.start(t["obs"]))
+            env.step(a, pt, ngt, None, fused=True)       # obs moves on while the gathers are in flight
+        assert g.in_flight() == k
+        assert len({o.data_ptr() for o in outs}) == k    # k distinct slots
+        g.wait()
+        assert g.in_flight() == 0
+        for j in range(k):
+            assert torch.equal(outs[j][:E], wants[j]), (rnd, j)
+
+
 def _stepping_env(E=4096, V=8, M=64):
     env = make_vec(E, V, M, seed=3, yaml=True)
     env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase()
@@ -184,6 +204,7 @@ def test_joint_obs_gather_on_device_single_process():
     _check_gather(g, env, a, pt, ngt)
     with pytest.raises(ValueError):
         g.start(env.tensors["obs"][:10])
+    _check_gathers_in_flight(rdist.JointObsGather(env.n_envs, env.n_veh, env.device, n_buffers=3), env, a, pt, ngt)
     # from a non-default main stream as well
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
@@ -208,6 +229,8 @@ def test_joint_obs_gather_on_device_rccl_one_rank():
         g = rdist.JointObsGather(env.n_envs, env.n_veh, env.device)
         assert g.collective and g.backend == "nccl" and g.world == 1
         _check_gather(g, env, a, pt, ngt)
+        # three RCCL gathers in flight before the first wait (round 3: one slot per gather in flight)
+        _check_gathers_in_flight(rdist.JointObsGather(env.n_envs, env.n_veh, env.device, n_buffers=3), env, a, pt, ngt)
         joint = rdist.gather_joint_obs(env.tensors["obs"])
         assert torch.equal(joint, env.tensors["obs"].reshape(env.n_envs, -1))
         with pytest.raises(ValueError):
@@ -638,3 +661,140 @@ def test_theta_by_index_is_bit_identical(V, M, E):
     assert not lz._theta_stale
     assert np.array_equal(sd["theta"].numpy(), cpu(ref.tensors["theta"]))
     same("bound launches", theta=True)
+
+
+# ---------------------------------------------------------------------------- full-size tests of what the big configs dispatch
+def test_full_size_properties_c5():
+    """BASELINE configs[4] (32 768 x 16 x 256, `step(bcd=True)` every step) through the kernels that configuration is
+    benchmarked on -- k_bcd_sweep8_pair (theta by index) + k_step_fused_lat<16,256,1,NT,TK> -- with size-independent
+    checks: which kernel ran (a threshold change must not silently untest them); whole batch == two half batches with
+    theta written eagerly, bit for bit (shard independence, lazy == eager theta, RNG keyed by global env id); the BCD
+    objective never decreases; kbit conservation; a 128-env shard (default cache policy, eager theta) equals the same
+    envs of the big batch and tracks the oracle's sweep -> gains -> step; checkpoint round trip.
+    Reference: Environment.py:208-231, 255-273, 547-731."""
+    from ris_vec_marl_amd import _native as N
+    E, V, M = 32768, 16, 256
+    rng = np.random.default_rng(5)
+    action = torch.from_numpy(rng.uniform(0, 1, (E, 2, V)).astype(np.float32)).cuda()
+    pnp, gnp = np.full((E, V), -1, dtype=np.int32), np.full(E, V - 2, dtype=np.int32)
+    pnp[:, 0], pnp[:, 1], pnp[:, 4], pnp[:, 9] = 1, 0 + (1 << 16), 9, 4 + (1 << 16)
+    partner, ng = torch.from_numpy(pnp).cuda(), torch.from_numpy(gnp).cuda()
+
+    def build(n, lo, lazy):
+        env = make_vec(n, V, M, seed=3, env_offset=lo, yaml=True)
+        env.lazy_theta = lazy
+        env.make_new_game()
+        for _ in range(2):
+            env.renew_positions()
+        env.compute_parms()
+        env.Random_phase()
+        return env
+
+    def objective(env):
+        t = env.tensors
+        th = torch.view_as_complex(t["theta"]); hr = torch.view_as_complex(t["h_r"]); b = torch.view_as_complex(t["b"])
+        return (th * hr.sum(1) * b[None]).sum(1).abs().double() ** 2
+
+    keys = ("reward", "gain", "data_buf", "mec_q", "rate", "metrics", "obs", "theta")
+    whole = build(E, 0, True)
+    B0 = whole.tensors["data_buf"].clone()
+    obj = [objective(whole)]
+    names = []
+    for i in range(3):
+        whole.step(action, partner, ng, None, fused=True, bcd=True)
+        names.append(N.last_kernel())
+        obj.append(objective(whole))                     # (materialises theta: the next step is by index again)
+    assert names[0] == "k_step_fused_lat<16,256,1,NT>", names          # first sweep: indices unknown, theta written
+    assert names[1] == names[2] == "k_step_fused_lat<16,256,1,NT,TK>", names
+    for a, b in zip(obj[:-1], obj[1:]):
+        assert bool((b >= a * (1 - 1e-5)).all())         # coordinate ascent (the check itself is a complex64 sum)
+    got = {k: whole.tensors[k].clone() for k in keys}
+    # kbit conservation of the last step: what left the backlog was processed locally or offloaded
+    m = got["metrics"]
+    assert bool((m[:, 1] >= 0).all()) and bool((m[:, 2] >= 0).all())
+    for lo, hi in ((0, E // 2), (E // 2, E)):
+        h = build(hi - lo, lo, False)
+        for i in range(3):
+            h.step(action[lo:hi], partner[lo:hi], ng[lo:hi], None, fused=True, bcd=True)
+        assert "NT" in N.last_kernel() and "TK" not in N.last_kernel()
+        for k in keys:
+            assert torch.equal(h.tensors[k], got[k][lo:hi]), k
+        del h
+        torch.cuda.empty_cache()
+    # a small shard: default cache policy, eager theta -- the same bits, and the oracle's sweep -> gains -> step
+    n = 128
+    small = build(n, 0, False)
+    p = orc.OracleParams.yaml_effective()
+    for i in range(3):
+        t = small.tensors
+        th_in = snap(c128(t["theta"]), 3)
+        Bq, Qq = cpu(t["data_buf"]).astype(np.float64), cpu(t["mec_q"]).astype(np.float64)
+        arrivals = orc.philox_arrivals(np.arange(n), V, small._steps, 3, p.rate)
+        o_th, o_idx, safe, h_, b_ = _bcd_step_reference(t, th_in, Bq, Qq, None, None, None, None, p, 3)
+        out = small.step(action[:n], partner[:n], ng[:n], None, fused=True, bcd=True)
+        assert N.last_kernel() == "k_step_fused_lat<16,256,1>"
+        th1 = c128(t["theta"])
+        assert safe.mean() > 0.97 and np.abs(th1 - o_th)[safe].max() <= 1.5e-7
+        g_dev = cpu(t["gain"]).astype(np.float64)
+        o = orc.step(Bq, Qq, g_dev, cpu(action[:n]).astype(np.float64), pnp[:n], gnp[:n], arrivals, p)
+        near_qos, near_other = step_mask(o, pnp[:n], g_dev, Qq)
+        okr = check_step(small, out, o, Bq, p, near_qos, near_other)
+        assert okr.mean() > 0.97
+    for k in keys:
+        assert torch.equal(small.tensors[k], got[k][:n]), k
+    # checkpoint round trip at full size (the indices are re-derived from the restored theta)
+    sd = whole.state_dict()
+    env2 = build(E, 0, True)
+    env2.load_state_dict(sd)
+    a = [x.clone() for x in whole.step(action, partner, ng, None, fused=True)]
+    b2 = [x.clone() for x in env2.step(action, partner, ng, None, fused=True)]
+    for x, y in zip(a, b2):
+        assert torch.equal(x, y)
+    del B0
+
+
+def test_full_size_dispatch_beyond_the_infinity_cache():
+    """262 144 x 8 x 64 (1.36 GB per step: bench.py's `hbm_only` leg) takes k_step_fused_lat<8,64,4,NT> by size; it must
+    equal the software pipeline (forced in a child process, where it runs with non-temporal loads as well) bit for
+    bit, and the whole batch must equal its two halves."""
+    import subprocess
+    import sys
+    import tempfile
+    from ris_vec_marl_amd import _native as N
+    E, V, M = 262144, 8, 64
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from tests.test_entry_points_hip import _big_rollout\n"
+        "from ris_vec_marl_amd import _native as N\n"
+        "out = _big_rollout(%d, %d, %d)\n"
+        "out['kernel'] = np.array(N.last_kernel())\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), E, V, M)
+    mine = _big_rollout(E, V, M)
+    assert N.last_kernel() == "k_step_fused_lat<8,64,4,NT>", N.last_kernel()
+    with tempfile.TemporaryDirectory() as tmp:
+        dst = os.path.join(tmp, "pipe.npz")
+        r = subprocess.run([sys.executable, "-c", code, dst], env=dict(os.environ, RISVEC_LAT_MAX_ENVS="0"), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        other = np.load(dst)
+        assert str(other["kernel"]).startswith("k_step_fused_pipe<8,64,2,MarlCore,NT>"), str(other["kernel"])
+        for k in mine:
+            assert np.array_equal(mine[k], other[k]), k
+    for lo, hi in ((0, E // 2), (E // 2, E)):
+        half = _big_rollout(hi - lo, V, M, lo=lo)
+        for k in mine:
+            assert np.array_equal(half[k], mine[k][lo:hi]), k
+
+
+def _big_rollout(E, V, M, lo=0, steps=2):
+    env = make_vec(E, V, M, seed=4, env_offset=lo, yaml=True)
+    env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase()
+    rng = np.random.default_rng(77)
+    action = rng.uniform(0, 1, (lo + E, 2, V)).astype(np.float32)[lo:]
+    partner = np.full((E, V), -1, dtype=np.int32); partner[:, 2], partner[:, 5] = 5, 2 + (1 << 16)
+    ng = np.full(E, V - 1, dtype=np.int32)
+    a, pt, ngt = torch.from_numpy(action).cuda(), torch.from_numpy(partner).cuda(), torch.from_numpy(ng).cuda()
+    for _ in range(steps):
+        env.step(a, pt, ngt, None, fused=True)
+    return {k: cpu(env.tensors[k]) for k in ("gain", "reward", "data_buf", "mec_q", "metrics", "obs")}
