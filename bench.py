@@ -295,6 +295,7 @@ class Case:
         if mode == "cached":
             env.update_channel_gains()
         self.multi = 1
+        self.ring_fused = False
         self.last_kernel = ""
         self.gather, self.gather_every = None, gather_every
         self.gather_note = "n/a (1 GPU)"
@@ -351,8 +352,14 @@ class Case:
             if marshal is not None:
                 marshal()
             replay = VecReplayBuffer(16 * E, 5, V + 2, V, device=device)
-            store = replay.bind_store(None, None if direct else a_store, env.tensors["metrics"], env.tensors["reward"],
-                                      env.tensors["obs"], grouper.mask, policy_out=(power_raw, probs) if direct else None)
+            # Default (round 3): the transition store rides in the step kernel (risvec_step_ring) where that form exists;
+            # RISVEC_BENCH_SEPARATE_STORE=1 keeps the two-launch form (step, then k_replay_store) for A/Bs.
+            self.ring_fused = (direct and not opts.steer and not opts.meter and V in (4, 8, 16) and mode in ("fused", "cached")
+                               and not os.environ.get("RISVEC_BENCH_SEPARATE_STORE")
+                               and (mode == "cached" or (V, M) in ((8, 64), (8, 36), (8, 40), (4, 16), (16, 64), (16, 256))))
+            if not self.ring_fused:
+                store = replay.bind_store(None, None if direct else a_store, env.tensors["metrics"], env.tensors["reward"],
+                                          env.tensors["obs"], grouper.mask, policy_out=(power_raw, probs) if direct else None)
         if grouper is None:
             group = None
         elif direct:
@@ -374,6 +381,10 @@ class Case:
                         metrics=torch.empty(T, E, 16, device=device)) if full else {}
             launch = env.bind_step_many(actions, partner, n_groups, None, metrics=full, obs=full, out=traj, fused=fused)
             self.multi = T
+        elif self.ring_fused:
+            both = env.bind_step_store(replay, power_raw, partner, n_groups, probs, grouper.mask, None, fused=fused, metrics=full)
+            self.step_store = both
+            launch = lambda: both(False, False)              # noqa: E731  (the untimed naming launch of run())
         else:
             launch = env.bind_step(power_raw if direct else action, partner, n_groups, None, fused=fused, bcd=bcd, metrics=full,
                                    power_w=opts.meter, obs=full, steer=opts.steer and fused, policy_action=direct)
@@ -399,7 +410,9 @@ class Case:
             if self.marshal is not None:
                 self.marshal()
             self.group(t)
-        if self.multi == 1 or i % self.multi == 0:      # --multi T: one launch advances the envs by T steps
+        if self.ring_fused:                             # step + transition store in one launch
+            self.step_store((i % L) == L - 1, (i % L) == 0)
+        elif self.multi == 1 or i % self.multi == 0:    # --multi T: one launch advances the envs by T steps
             self.launch()
         if self.store is not None:
             self.store(done=(i % L) == L - 1, use_mask=(i % L) == 0)
@@ -692,6 +705,7 @@ def main() -> None:
     case = (StubCase if STUB else Case)(E, V, M, args.mode, device, rank, world, start, args, args.gather_every)
     dt, kernel_ms = case.run(args.steps, args.warmup, world)
     gather_ok = getattr(case, "gather_ok", True)
+    case_ring_fused = getattr(case, "ring_fused", False)
     fused, bcd, full = case.fused, case.bcd, case.full
     per_env = case.per_env_bytes()
     gather_note = case.gather_note
@@ -748,7 +762,9 @@ def main() -> None:
                    "noma_grouping": ("device, every step, 100-step episodes (config.yaml pairing keys)"
                                      if args.noma else "synthetic fixed groups"),
                    "replay": ("%sHBM replay ring store every step (%d B per transition)"
-                              % ("marshal launch + " if (args.marshal or args.policy) else "policy outputs read in place, ",
+                              % ("marshal launch + " if (args.marshal or args.policy) else
+                                 ("transition written by the step kernel (risvec_step_ring), " if case_ring_fused else
+                                  "policy outputs read in place, "),
                                  4 * (10 * V + V * (V + 2) + V + 1 + V * V) + 1) if args.replay else "off"),
                    "policy": "BatchedPolicy 8x(5-512-256), every step" if args.policy else "synthetic outputs",
                    "steering_form": bool(args.steer and fused),

@@ -481,6 +481,30 @@ int risvec_replay_store(const RisVecReplay *rb, int64_t mem_cntr, int32_t n, con
                         const uint8_t *done, int32_t done_all, const uint8_t *mask, float *state_carry,
                         risvec_stream_t stream);
 
+/* The rollout's transition store FUSED into the step (round 3): one launch runs step() (fused != 0: with the RIS
+ * cascaded gains, as risvec_step_fused; 0: on the cached gains, as risvec_step) and appends this step's n_envs
+ * transitions to the ring -- what risvec_step* followed by risvec_replay_store_policy do in two launches, bit for bit
+ * (marl_train_bcd.py:1776-1799, buffer.py:16-25):
+ *   state      <- state.obs as the kernel finds it (the observation the policy acted on: keep it current),
+ *   action     <- per agent [probs_i with zero diagonal | raw power_i] from `action` (the raw policy output [E,V,2]:
+ *                 flags must hold RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS) and ring->probs [E,V,V],
+ *   reward_l / reward_g / state_ <- this step's per-user rewards, their mean, the new observation,
+ *   done       <- ring->done for every transition, mask <- ring->mask [E,V,V] bytes or all ones when NULL.
+ * Needs n_veh in {4, 8, 16}, rb.n_agents = n_veh, rb.input_shape = 5, rb.n_actions = n_veh + 2, n_envs <= mem_size;
+ * fused != 0 additionally needs a shape with a software-pipelined kernel (RISVEC_ERR_UNSUPPORTED otherwise: use
+ * the two-launch form).  The caller advances its mem_cntr by n_envs. */
+typedef struct RisVecStepRing {
+    RisVecReplay rb;
+    int64_t mem_cntr;
+    const float *probs;
+    const uint8_t *mask;
+    int32_t done;
+    int32_t reserved;
+} RisVecStepRing;
+int risvec_step_ring(const RisVecState *s, const RisVecParams *p, const RisVecStepRing *ring, const float *action,
+                     const int32_t *partner, const int32_t *n_groups, const int32_t *arrivals, uint64_t seed,
+                     uint32_t counter, uint32_t flags, int32_t fused, risvec_stream_t stream);
+
 /* risvec_replay_store with the action row built in the store kernel from the policy outputs -- power_raw [n,A,2],
  * probs [n,A,A]: per agent [probs_i with zero diagonal | raw power_i], exactly the action_store row of
  * risvec_marshal_actions (TRAIN:1386-1390, 1776-1784) -- so a rollout step needs no marshalling launch: the env

@@ -120,6 +120,11 @@ class RisVecReplay(C.Structure):
     ]
 
 
+class RisVecStepRing(C.Structure):
+    _fields_ = [("rb", RisVecReplay), ("mem_cntr", C.c_int64), ("probs", _FP), ("mask", _FP), ("done", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 NOMA_MAX_VEH = 16
 NOMA_HAS_LAST, NOMA_UNSTICK_USED, NOMA_HAS_GROUPS = 1, 2, 4
 
@@ -158,6 +163,8 @@ _PROTOS = {
                                    C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
     "risvec_step_fused_bcd": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), _FP, _FP,
                                         _FP, _FP, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
+    "risvec_step_ring": (C.c_int, [C.POINTER(RisVecState), C.POINTER(RisVecParams), C.POINTER(RisVecStepRing), _FP, _FP, _FP,
+                                   _FP, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, _FP]),
     "risvec_noma_default_params": (None, [C.POINTER(RisVecNomaParams), C.c_int32]),
     "risvec_noma_begin_episode": (C.c_int, [C.POINTER(RisVecNomaState), _FP]),
     "risvec_noma_mask": (C.c_int, [C.POINTER(RisVecNomaState), _FP, _FP, C.c_double, C.c_int32, _FP]),

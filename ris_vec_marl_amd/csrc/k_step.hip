@@ -40,7 +40,8 @@ k_gain(Dims d, const float* __restrict__ h_r, const float* __restrict__ theta,
 }
 
 // K4: standalone step kernel (cached gains; the reference's per-step cadence)
-template <int VP>
+// RING: the env's replay transition is written from here too (StepArgs::ring; marl_train_bcd.py:1776-1799)
+template <int VP, bool RING = false>
 __global__ void __launch_bounds__(kBlock)
 k_step(Dims d, RisVecParams P, StepArgs A) {
     RISVEC_ARGS_IN_ONE_TRIP("s"(d.E), "s"(d.V), "s"(A.flags), "s"(A.action), "s"(A.data_buf), "s"(A.partner), "s"(A.n_groups),
@@ -51,7 +52,12 @@ k_step(Dims d, RisVecParams P, StepArgs A) {
     const bool active = e < d.E && v < d.V;
     const StepIn in = load_step_in(d, A, e, v, active);
     const float g = active ? A.gain[(long long)e * d.V + v] : 0.f;
-    step_core<VP, false, true>(d, P, A, e, v, active, g, in);
+    if constexpr (RING) {
+        const RingIn<VP> rin = load_ring_in<VP>(d, A, e, v, active);
+        step_core<VP, false, true, RingIn<VP>>(d, P, A, e, v, active, g, in, nullptr, &rin);
+    } else {
+        step_core<VP, false, true>(d, P, A, e, v, active, g, in);
+    }
 }
 
 // K4 over T steps: the driver's own cadence (marl_train_bcd.py:1304-1611: step() every step, the channel gains only every
@@ -268,10 +274,20 @@ static hipError_t launch_step_vp(const RisVecState& s, const RisVecParams& p, co
     const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
     const Dims d = dims_of(s);
     if (!fused) {
+        if (a.ring.state_memory) {
+            if constexpr (VP == 4 || VP == 8 || VP == 16) {
+                hipLaunchKernelGGL((k_step<VP, true>), dim3(grid), dim3(kBlock), 0, st, d, p, a);
+                note_kernel("k_step<%d,RING>", VP);
+                return hipGetLastError();
+            } else {
+                return hipErrorNotSupported;
+            }
+        }
         hipLaunchKernelGGL((k_step<VP>), dim3(grid), dim3(kBlock), 0, st, d, p, a);
         note_kernel("k_step<%d>", VP);
         return hipGetLastError();
     }
+    if (a.ring.state_memory) return hipErrorNotSupported;      // fused + ring: the software pipeline's ring form only
     const bool even = (s.n_ris & 1) == 0;
     const int g = pick_group(s.n_ris, even ? 2 : 1, VP);
 #define RISVEC_FUSED(GG)                                                                          \
@@ -291,9 +307,15 @@ static hipError_t launch_step_vp(const RisVecState& s, const RisVecParams& p, co
 
 hipError_t launch_step(const RisVecState& s, const RisVecParams& p, const float* action,
                        const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals,
-                       uint64_t seed, uint32_t counter, uint32_t flags, bool fused, hipStream_t st) {
+                       uint64_t seed, uint32_t counter, uint32_t flags, bool fused, hipStream_t st, const StepRing* ring) {
     StepArgs a = make_step_args(s, action, partner, n_groups, arrivals, seed, counter,
                                 flags & ~(uint32_t)(RISVEC_STEP_STEER | RISVEC_STEP_THETA_BY_INDEX));
+    if (ring) {
+        // the transition store rides in the step kernel: the software pipeline's ring form (compile-time shapes) or the
+        // cached-gain k_step<VP, RING>; no other member of the family carries it
+        a.ring = *ring;
+        if (fused) return launch_step_fused_pipe_ring(s, p, a, st);
+    }
     if (fused && (flags & RISVEC_STEP_THETA_BY_INDEX)) {
         // theta is kept by index: only the latency-shaped family has that form (the API checked the shape)
         a.theta_k = s.theta_idx;

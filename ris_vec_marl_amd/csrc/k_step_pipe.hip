@@ -331,6 +331,18 @@ hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, c
     return dispatch_pipe<MarlCore>(s, p, a, st);
 }
 
+hipError_t launch_step_fused_pipe_ring(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st) {
+    if (pipe_disabled()) return hipErrorNotSupported;
+    const int V = s.n_veh, M = s.n_ris;
+    if (V == 8 && M == 64) return launch_pipe<8, 64, 2, MarlRingCore<8>>(s, p, a, st);
+    if (V == 8 && M == 36) return launch_pipe<8, 36, 2, MarlRingCore<8>>(s, p, a, st);
+    if (V == 8 && M == 40) return launch_pipe<8, 40, 2, MarlRingCore<8>>(s, p, a, st);
+    if (V == 4 && M == 16) return launch_pipe<4, 16, 4, MarlRingCore<4>>(s, p, a, st);
+    if (V == 16 && M == 64) return launch_pipe<16, 64, 2, MarlRingCore<16>>(s, p, a, st);
+    if (V == 16 && M == 256) return launch_pipe<16, 256, 2, MarlRingCore<16>>(s, p, a, st);
+    return hipErrorNotSupported;
+}
+
 hipError_t launch_sarl_pipe(const RisVecState& s, const RisVecSarlParams& p, const SarlArgs& a, hipStream_t st) {
     return dispatch_pipe<SarlCore>(s, p, a, st);
 }

@@ -417,6 +417,46 @@ int risvec_step_fused_bcd(const RisVecState* s, const RisVecParams* p, const flo
                                                     counter, flags, (hipStream_t)stream));
 }
 
+int risvec_step_ring(const RisVecState* s, const RisVecParams* p, const RisVecStepRing* ring, const float* action,
+                     const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals, uint64_t seed,
+                     uint32_t counter, uint32_t flags, int32_t fused, risvec_stream_t stream) {
+    const char* fn = "risvec_step_ring";
+    if (!p) return fail(RISVEC_ERR_ARG, "%s: params is NULL", fn);
+    if (!ring) return fail(RISVEC_ERR_ARG, "%s: ring is NULL", fn);
+    if (int rc = check_common(fn, s, p)) return rc;
+    if (int rc = check_step(fn, s, action, partner, n_groups, arrivals, flags, fused != 0)) return rc;
+    const uint32_t need = RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS;
+    if ((flags & need) != need)
+        return fail(RISVEC_ERR_ARG, "%s: flags must hold RISVEC_STEP_POLICY_ACTION | RISVEC_STEP_OBS (the ring stores the raw policy "
+                    "output and both observations)", fn);
+    if (flags & (RISVEC_STEP_STEER | RISVEC_STEP_THETA_BY_INDEX | RISVEC_STEP_REUSE_COLSUM | RISVEC_STEP_REUSE_SSUM | RISVEC_STEP_REUSE_IDX))
+        return fail(RISVEC_ERR_ARG, "%s: steering / theta-by-index / BCD flags (0x%x) are not accepted here", fn, flags);
+    const RisVecReplay& rb = ring->rb;
+    const int V = s->n_veh;
+    if (V != 4 && V != 8 && V != 16)
+        return fail(RISVEC_ERR_UNSUPPORTED, "%s: n_veh=%d (the fused transition store exists for 4, 8 and 16 vehicles)", fn, V);
+    if (rb.n_agents != V || rb.input_shape != 5 || rb.n_actions != V + 2)
+        return fail(RISVEC_ERR_SHAPE, "%s: the ring must have n_agents = n_veh = %d, input_shape = 5, n_actions = %d (got %d, %d, %d)",
+                    fn, V, V + 2, rb.n_agents, rb.input_shape, rb.n_actions);
+    if (rb.mem_size < s->n_envs) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d transitions do not fit mem_size=%lld", fn, s->n_envs,
+                                             (long long)rb.mem_size);
+    if (ring->mem_cntr < 0) return fail(RISVEC_ERR_ARG, "%s: mem_cntr < 0", fn);
+    REQ_PTR(rb.state_memory, "ring.state_memory"); REQ_PTR(rb.action_memory, "ring.action_memory");
+    REQ_PTR(rb.reward_global_memory, "ring.reward_global_memory"); REQ_PTR(rb.reward_local_memory, "ring.reward_local_memory");
+    REQ_PTR(rb.new_state_memory, "ring.new_state_memory"); REQ_PTR(rb.terminal_memory, "ring.terminal_memory");
+    REQ_PTR(rb.mask_memory, "ring.mask_memory"); REQ_PTR(ring->probs, "ring.probs"); OPT_PTR(ring->mask, "ring.mask");
+    REQ_PTR(s->obs, "state.obs");
+    risvec::StepRing r{rb.state_memory, rb.action_memory, rb.reward_global_memory, rb.reward_local_memory, rb.new_state_memory,
+                       rb.terminal_memory, rb.mask_memory, ring->probs, ring->mask, (long long)(ring->mem_cntr % rb.mem_size),
+                       (long long)rb.mem_size, ring->done ? 1 : 0};
+    const hipError_t err = risvec::launch_step(*s, *p, action, partner, n_groups, arrivals, seed, counter, flags, fused != 0,
+                                               (hipStream_t)stream, &r);
+    if (err == hipErrorNotSupported)
+        return fail(RISVEC_ERR_UNSUPPORTED, "%s: no fused-gains kernel with the transition store at n_veh=%d, n_ris=%d (use "
+                    "risvec_step_fused + risvec_replay_store_policy)", fn, V, s->n_ris);
+    return finish(fn, err);
+}
+
 // ---------------------------------------------------------------------------------------------
 // NOMA grouping stage (f2)
 // ---------------------------------------------------------------------------------------------

@@ -22,9 +22,11 @@ hipError_t launch_random_phase(const RisVecState& s, const int32_t* idx, uint64_
                                uint32_t counter, hipStream_t st);
 
 hipError_t launch_gain(const RisVecState& s, const RisVecParams& p, hipStream_t st);
+struct StepRing;
 hipError_t launch_step(const RisVecState& s, const RisVecParams& p, const float* action,
                        const int32_t* partner, const int32_t* n_groups, const int32_t* arrivals,
-                       uint64_t seed, uint32_t counter, uint32_t flags, bool fused, hipStream_t st);
+                       uint64_t seed, uint32_t counter, uint32_t flags, bool fused, hipStream_t st,
+                       const StepRing* ring = nullptr);
 
 hipError_t launch_data_rate(const RisVecState& s, const RisVecParams& p, const float* p_off,
                             const int32_t* partner, const int32_t* n_groups, float* rate_out,

@@ -129,4 +129,38 @@ inline const Tuning& tuning() {
 
 inline int num_cus() { return tuning().cus; }
 
+// MarlCore + the transition store (StepArgs::ring): the ring's per-lane inputs (the observation being replaced, the
+// agent's partner-probability row, its mask row) are prefetched one group ahead with the step inputs.
+template <int VPC>
+struct MarlRingCore {
+    static const char* name() { return "MarlCore+ring"; }
+    using Params = RisVecParams;
+    using Args = StepArgs;
+    struct In { StepIn s; RingIn<VPC> r; };
+    static __device__ __forceinline__ In load(const Dims& d, const Args& A, int e, int v, bool active) {
+        return In{load_step_in(d, A, e, v, active), load_ring_in<VPC>(d, A, e, v, active)};
+    }
+    static __device__ __forceinline__ void hold(const In& in) {
+        MarlCore::hold(in.s);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) asm volatile("" ::"v"(in.r.so[k]));
+#pragma unroll
+        for (int k = 0; k < VPC; ++k) asm volatile("" ::"v"(in.r.prow[k]));
+#pragma unroll
+        for (int k = 0; k < VPC / 4; ++k) asm volatile("" ::"v"(in.r.mk[k]));
+    }
+    template <int VP>
+    static __device__ __forceinline__ void run(const Dims& d, const Params& P, const Args& A, int e, int v,
+                                               bool active, float2 img, const In& in) {
+        static_assert(VP == VPC, "ring core instantiated for another V");
+        float g = 0.f;
+        if (active) {
+            const long long idx = (long long)e * d.V + v;
+            g = gain_from_img(img, in.s.pl, A.h_d, idx);
+            A.gain[idx] = g;
+        }
+        step_core<VP, false, false, RingIn<VPC>>(d, P, A, e, v, active, g, in.s, nullptr, &in.r);
+    }
+};
+
 }  // namespace risvec

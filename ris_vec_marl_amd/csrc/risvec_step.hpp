@@ -5,6 +5,8 @@
 // step ENV:547-731; observation marl_train_bcd.py:819-827, action map :1601-1608.
 #pragma once
 
+#include <type_traits>
+
 #include "risvec_launch.hpp"
 
 namespace risvec {
@@ -22,6 +24,24 @@ namespace risvec {
     "s"((P).w_e), "s"((P).reward_clip), "s"((P).poisson_cdf[0]), "s"((P).poisson_cdf[1]), "s"((P).poisson_cdf[2]),    \
     "s"((P).poisson_cdf[3]), "s"((P).poisson_cdf[4]), "s"((P).poisson_cdf[5]), "s"((P).poisson_cdf[6]),               \
     "s"((P).poisson_cdf[7])
+
+// The rollout's transition store, fused into the step (round 3; marl_train_bcd.py:1776-1799, buffer.py:16-25): the
+// kernel that has the new observation, the rewards and the raw policy output of (env, vehicle) in registers also
+// writes that agent's slice of the env's replay row -- what k_replay_store did in a second launch after re-reading
+// obs / reward / metrics from HBM.  Row layout of buffer.py's seven arrays with input_shape = 5, n_actions = V + 2.
+struct StepRing {
+    float* state_memory;            // [mem_size, 5V]       the observation BEFORE this step (state.obs as the kernel finds it)
+    float* action_memory;           // [mem_size, V(V+2)]   per agent [probs_i with zero diagonal | raw power_i]
+    float* reward_global_memory;    // [mem_size]
+    float* reward_local_memory;     // [mem_size, V]
+    float* new_state_memory;        // [mem_size, 5V]
+    uint8_t* terminal_memory;       // [mem_size]
+    float* mask_memory;             // [mem_size, V V]
+    const float* probs;             // [E, V, V] partner probabilities of the policy
+    const uint8_t* mask;            // [E, V, V] NOMA mask bytes, or nullptr = all ones (marl_train_bcd.py:1786-1787)
+    long long head, mem_size;       // ring row of env 0 (mem_cntr % mem_size), rows in the ring
+    int done;                       // terminal flag of this step's transitions
+};
 
 struct StepArgs {
     const float* action;
@@ -51,6 +71,7 @@ struct StepArgs {
     // (state.theta_idx); nullptr = read the complex64 theta
     const uint8_t* theta_k;
     int theta_k_stride;
+    StepRing ring;                  // used by the RING instances of the kernels only
 };
 
 // ---------------------------------------------------------------------------
@@ -301,6 +322,76 @@ struct StepCarry {
 // latency-shaped kernels); TM = false: one butterfly per metric, lane 0 stores four float4 (the software pipeline:
 // its 16-byte stores are a little kinder to a kernel that is busy streaming h_r).  Same values bit for bit.
 // ---------------------------------------------------------------------------
+// per-lane inputs of the fused transition store, requested with the step inputs
+template <int VP>
+struct RingIn {
+    float so[5];                    // the observation this step replaces
+    float prow[VP];                 // probs[e, v, :]
+    unsigned mk[VP / 4];            // mask[e, v, :] bytes
+};
+
+template <int VP>
+__device__ __forceinline__ RingIn<VP> load_ring_in(const Dims& d, const StepArgs& A, int e, int v, bool active) {
+    RingIn<VP> r;
+    const long long idx = active ? (long long)e * VP + v : 0;       // inactive lanes re-read (env 0, vehicle 0): no branch
+    const float* o = A.obs + idx * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r.so[k] = o[k];
+    const float4* p4 = reinterpret_cast<const float4*>(A.ring.probs + idx * VP);
+#pragma unroll
+    for (int k = 0; k < VP / 4; ++k) {
+        const float4 x = p4[k];
+        r.prow[4 * k] = x.x; r.prow[4 * k + 1] = x.y; r.prow[4 * k + 2] = x.z; r.prow[4 * k + 3] = x.w;
+    }
+    // all-ones without a mask: the address is selected, not the load (the probs row stands in; its value is ignored)
+    const unsigned* m4 = A.ring.mask ? reinterpret_cast<const unsigned*>(A.ring.mask + idx * VP)
+                                     : reinterpret_cast<const unsigned*>(A.ring.probs + idx * VP);
+#pragma unroll
+    for (int k = 0; k < VP / 4; ++k) r.mk[k] = m4[k];
+    return r;
+}
+
+__device__ __forceinline__ void ring_st(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void ring_st2(float* p, float a, float b) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f t; t.x = a; t.y = b;
+    __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(p));
+}
+__device__ __forceinline__ void ring_st4(float* p, float a, float b, float c, float dd) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f t; t.x = a; t.y = b; t.z = c; t.w = dd;
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+
+// this agent's slice of its env's replay row (the ring is write-once data: non-temporal stores)
+template <int VP>
+__device__ __forceinline__ void ring_store(const StepArgs& A, int e, int v, const RingIn<VP>& R, const StepIn& in, float Bn,
+                                           float data_t, float data_p, float rate, float rew) {
+    const StepRing& G = A.ring;
+    long long row = G.head + e;
+    row = row >= G.mem_size ? row - G.mem_size : row;
+    float* s0 = G.state_memory + row * (5 * VP) + v * 5;
+    float* s1 = G.new_state_memory + row * (5 * VP) + v * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ring_st(s0 + k, R.so[k]);
+    ring_st(s1 + 0, Bn * 0.1f); ring_st(s1 + 1, data_t * 0.1f); ring_st(s1 + 2, data_p * 0.1f); ring_st(s1 + 3, 0.f);
+    ring_st(s1 + 4, rate * 0.05f);
+    ring_st(G.reward_local_memory + row * VP + v, rew);
+    float* a = G.action_memory + row * (VP * (VP + 2)) + v * (VP + 2);       // 8-byte aligned: VP + 2 is even
+#pragma unroll
+    for (int k = 0; k < VP; k += 2) ring_st2(a + k, k == v ? 0.f : R.prow[k], k + 1 == v ? 0.f : R.prow[k + 1]);
+    ring_st2(a + VP, in.a0, in.a1);                                            // the raw policy output (TRAIN:1777-1782)
+    float* m = G.mask_memory + row * (VP * VP) + v * VP;
+    const bool ones = G.mask == nullptr;
+#pragma unroll
+    for (int k = 0; k < VP / 4; ++k) {
+        const unsigned w = R.mk[k];
+        ring_st4(m + 4 * k, (ones || (w & 0xFFu)) ? 1.f : 0.f, (ones || (w & 0xFF00u)) ? 1.f : 0.f,
+                 (ones || (w & 0xFF0000u)) ? 1.f : 0.f, (ones || (w & 0xFF000000u)) ? 1.f : 0.f);
+    }
+    if (v == 0) G.terminal_memory[row] = (uint8_t)(G.done ? 1 : 0);
+}
+
 struct StepPre {
     float pw0, pw1;          // transmit / (unused) second power, W                     ENV:555-561
     float f;                 // local CPU frequency                                      ENV:572-580
@@ -380,14 +471,17 @@ __device__ __forceinline__ StepPre step_pre(const Dims& d, const RisVecParams& P
     return r;
 }
 
-template <int VP, bool TRAJ = false, bool TM = false>
+struct NoRing {};
+
+template <int VP, bool TRAJ = false, bool TM = false, class RIN = NoRing>
 __device__ __forceinline__ StepCarry step_tail(const Dims& d, const RisVecParams& P, const StepArgs& A,
                                                int e, int v, bool active, float gain, const StepIn& in,
-                                               const StepPre& pre, const StepTraj* tj = nullptr) {
+                                               const StepPre& pre, const StepTraj* tj = nullptr, const RIN* rin = nullptr) {
     // No implicit contraction: whether `a * b + c` became one fused instruction used to depend on what else the
     // compiler saw around it (the early step_pre of the latency-shaped kernels vs the back-to-back form of the
     // software pipeline), and the kernels must agree to the last bit.  The fusions worth having are written out.
 #pragma clang fp contract(off)
+    constexpr bool RING = !std::is_same<RIN, NoRing>::value;
     const int V = d.V;
     const long long idx = (long long)e * V + v;
     const float eps = 1e-12f;
@@ -477,6 +571,7 @@ __device__ __forceinline__ StepCarry step_tail(const Dims& d, const RisVecParams
             A.power_w[(long long)e * 2 * V + V + v] = E_loc * inv_tf;
         }
         if (v == 0) A.mec_q[e] = Q;
+        if constexpr (RING) ring_store<VP>(A, e, v, *rin, in, Bn, data_t, data_p, rate, rew);
     }
     if constexpr (TRAJ) {
         if (active) {
@@ -514,6 +609,13 @@ __device__ __forceinline__ StepCarry step_tail(const Dims& d, const RisVecParams
                 const bool is_sum = slot == 1 || slot == 2 || slot == 3 || slot == 9;
                 const float val = part[0] * (is_sum ? 1.f : inv_v);
                 if (active) {
+                    if constexpr (RING) {
+                        if (slot == 0) {
+                            long long row = A.ring.head + e;
+                            row = row >= A.ring.mem_size ? row - A.ring.mem_size : row;
+                            ring_st(A.ring.reward_global_memory + row, val);
+                        }
+                    }
                     if (store_state) A.metrics[(long long)e * RISVEC_METRICS + slot] = val;
                     if constexpr (TRAJ) {
                         if (tj->metrics) tj->metrics[(long long)e * RISVEC_METRICS + slot] = val;
@@ -524,6 +626,13 @@ __device__ __forceinline__ StepCarry step_tail(const Dims& d, const RisVecParams
         }
     }
     const float rew_sum = gsum<VP>(active ? rew : 0.f);
+    if constexpr (RING) {
+        if (active && v == 0) {
+            long long row = A.ring.head + e;
+            row = row >= A.ring.mem_size ? row - A.ring.mem_size : row;
+            ring_st(A.ring.reward_global_memory + row, rew_sum * inv_v);
+        }
+    }
     if (A.flags & RISVEC_STEP_METRICS) {
         const float z = 0.f;
         const float s_off = gsum<VP>(active ? off : z);
@@ -562,12 +671,12 @@ __device__ __forceinline__ StepCarry step_tail(const Dims& d, const RisVecParams
     return StepCarry{Bn, Q};
 }
 
-template <int VP, bool TRAJ = false, bool TM = false>
+template <int VP, bool TRAJ = false, bool TM = false, class RIN = NoRing>
 __device__ __forceinline__ StepCarry step_core(const Dims& d, const RisVecParams& P, const StepArgs& A,
                                                int e, int v, bool active, float gain, const StepIn& in,
-                                               const StepTraj* tj = nullptr) {
+                                               const StepTraj* tj = nullptr, const RIN* rin = nullptr) {
     const StepPre pre = step_pre<TRAJ>(d, P, A, e, v, active, in);
-    return step_tail<VP, TRAJ, TM>(d, P, A, e, v, active, gain, in, pre, tj);
+    return step_tail<VP, TRAJ, TM, RIN>(d, P, A, e, v, active, gain, in, pre, tj, rin);
 }
 
 inline StepArgs make_step_args(const RisVecState& s, const float* action, const int32_t* partner,
@@ -581,6 +690,7 @@ inline StepArgs make_step_args(const RisVecState& s, const float* action, const 
     a.over_power = s.over_power; a.obs = s.obs; a.metrics = s.metrics; a.power_w = s.power_w;
     a.seed = seed; a.counter = counter; a.flags = flags;
     a.theta_k = nullptr; a.theta_k_stride = 0;
+    a.ring = StepRing{};
     return a;
 }
 
@@ -589,6 +699,7 @@ inline StepArgs make_step_args(const RisVecState& s, const float* action, const 
 hipError_t launch_step_fused_pipe(const RisVecState& s, const RisVecParams& p, const StepArgs& a,
                                   hipStream_t st);
 hipError_t launch_gain_pipe(const RisVecState& s, hipStream_t st);
+hipError_t launch_step_fused_pipe_ring(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st);
 // latency-shaped single-group kernels for small batches and the multi-step launch (k_step_lat.hip)
 hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, const StepArgs& a, hipStream_t st);
 bool step_fused_lat_covers(int V, int M);

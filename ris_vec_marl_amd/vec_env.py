@@ -623,6 +623,54 @@ class VecEnviron(ParamAttrs):
         launch.inputs = keep
         return launch
 
+    def bind_step_store(self, replay, power_raw: torch.Tensor, partner: torch.Tensor, n_groups: torch.Tensor,
+                        probs: torch.Tensor, mask: Optional[torch.Tensor] = None, arrivals: Optional[torch.Tensor] = None,
+                        fused: bool = True, metrics: bool = True, power_w: bool = False):
+        """The rollout step with the transition store fused in (`risvec_step_ring`; marl_train_bcd.py:1601-1611,
+        1776-1799): ONE launch runs `step()` on the raw policy output `power_raw` [E,V,2] and appends this step's E
+        transitions to `replay` (a `VecReplayBuffer` with input_shape 5, n_actions V+2, n_agents V) -- state = the
+        observation the env holds when the launch starts, action row = [probs_i with zero diagonal | raw power_i],
+        rewards and the new observation straight from the step's registers.  Ring contents and env tensors are those
+        of `bind_step(policy_action=True)` followed by `replay.bind_store(..., policy_out=(power_raw, probs))`, bit
+        for bit.  Returns `launch(done=False, use_mask=True)`; all tensors are read in place on every call.
+        fused=True needs a shape with a software-pipelined kernel ((8,64), (8,36), (8,40), (4,16), (16,64), (16,256));
+        fused=False steps on the cached gains, any M."""
+        self._ensure_device()
+        E, V = self.n_envs, self.n_veh
+        a = self._bound(power_raw, torch.float32, (E, V, 2), "power_raw")
+        pt = self._bound(partner, torch.int32, (E, V), "partner")
+        ng = self._bound(n_groups, torch.int32, (E,), "n_groups")
+        pr = self._bound(probs, torch.float32, (E, V, V), "probs")
+        mk = self._bound(mask, torch.uint8, (E, V, V), "mask")
+        ar = self._bound(arrivals, torch.int32, (E, V), "arrivals")
+        if replay.device != self.device or replay.n_agents != V or replay.input_shape != 5 or replay.n_actions != V + 2:
+            raise ValueError("bind_step_store: the replay buffer must live on %s with n_agents=%d, input_shape=5, n_actions=%d"
+                             % (self.device, V, V + 2))
+        flags = ((N.STEP_METRICS if metrics else 0) | (N.STEP_POWER_W if power_w else 0) | N.STEP_OBS | N.STEP_POLICY_ACTION)
+        ring = N.RisVecStepRing()
+        ring.rb = replay._c
+        ring.probs, ring.mask = pr.data_ptr(), None
+        fn, cs, seed, stream = N.load().risvec_step_ring, C.byref(self._cstate), C.c_uint64(self.seed), self._stream()
+        pa, pp, pn, par, pmask = _dev_ptr(a), _dev_ptr(pt), _dev_ptr(ng), _dev_ptr(ar), _dev_ptr(mk)
+        fz = 1 if fused else 0
+
+        def launch(done: bool = False, use_mask: bool = True) -> None:
+            if self._obs_stale:
+                self.observe()                   # the ring's `state` is the observation tensor as the kernel finds it
+            if fused:
+                self._sync_theta()
+            ring.mem_cntr, ring.done = replay.mem_cntr, 1 if done else 0
+            ring.mask = pmask if use_mask else None
+            rc = fn(cs, C.byref(self._p()), C.byref(ring), pa, pp, pn, par, seed, self._steps, flags, fz, stream)
+            if rc:
+                N.check(rc)
+            replay.mem_cntr += E
+            self._steps += 1
+            self._obs_stale = False
+
+        launch.inputs = (a, pt, ng, pr, mk, ar, ring, replay)
+        return launch
+
     # ------------------------------------------------------------------ driver-side helpers
     def observe(self) -> torch.Tensor:
         """marl_train_bcd.py:819-827 for all agents: [E,V,5].  After a step the kernel has

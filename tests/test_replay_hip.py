@@ -220,3 +220,62 @@ def test_rollout_without_a_marshal_launch_is_identical(V, M):
     assert torch.equal(buf3.action_memory[:E], a_store)
     with pytest.raises(ValueError):
         buf3.store_batch(state_old, None, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"])
+
+
+@pytest.mark.parametrize("V,M,fused", [(8, 64, True), (8, 36, True), (4, 16, True), (16, 64, True), (8, 64, False), (16, 50, False),
+                                       (4, 30, False)])
+def test_step_with_the_transition_store_fused_in(V, M, fused):
+    """`bind_step_store` (risvec_step_ring): ONE launch = step() + this step's E transitions appended to the ring
+    (marl_train_bcd.py:1601-1611, 1776-1799; buffer.py:16-25).  Env tensors and all seven ring arrays must equal the
+    two-launch form -- `bind_step(policy_action=True)` then `store_batch(state = the observation before the step,
+    policy_out = (power_raw, probs))` -- bit for bit, through a ring wrap, with and without the NOMA mask, with the
+    terminal flag, from a reset (the first `state` is the observation assembled from the reset state)."""
+    from ris_vec_marl_amd import VecEnviron, VecReplayBuffer, apply_yaml_config, reference_lanes
+    from ris_vec_marl_amd import _native as N
+    E, T = 777, 7
+    L = reference_lanes()
+    gen = torch.Generator(device=DEV); gen.manual_seed(11 + V + M)
+    power = [torch.rand(E, V, 2, device=DEV, generator=gen) * 2.4 - 1.2 for _ in range(T)]
+    probs = [torch.softmax(torch.randn(E, V, V, device=DEV, generator=gen), -1) for _ in range(T)]
+    mask = (torch.rand(E, V, V, device=DEV, generator=gen) < 0.6).to(torch.uint8)
+    partner = torch.full((E, V), -1, dtype=torch.int32, device=DEV); partner[:, 0] = 1; partner[:, 1] = (1 << 16)
+    ng = torch.full((E,), V - 1, dtype=torch.int32, device=DEV)
+
+    def build():
+        env = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3, n_envs=E,
+                         device=DEV, seed=21)
+        apply_yaml_config(env, None)
+        env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase(); env.update_channel_gains()
+        return env, VecReplayBuffer(int(2.5 * E), 5, V + 2, V, device=DEV)      # wraps during step 3
+
+    # (a) two launches per step
+    env, buf = build()
+    pw, pr = torch.empty(E, V, 2, device=DEV), torch.empty(E, V, V, device=DEV)
+    step = env.bind_step(pw, partner, ng, None, fused=fused, policy_action=True, power_w=False)
+    for t in range(T):
+        pw.copy_(power[t]); pr.copy_(probs[t])
+        before = env.observe().clone()
+        step()
+        buf.store_batch(before, None, env.tensors["metrics"], env.tensors["reward"], env.tensors["obs"], t == T - 1,
+                        mask if t % 2 == 0 else None, policy_out=(pw, pr))
+    # (b) one launch per step
+    env2, buf2 = build()
+    pw2, pr2 = torch.empty(E, V, 2, device=DEV), torch.empty(E, V, V, device=DEV)
+    both = env2.bind_step_store(buf2, pw2, partner, ng, pr2, mask, fused=fused)
+    for t in range(T):
+        pw2.copy_(power[t]); pr2.copy_(probs[t])
+        both(done=t == T - 1, use_mask=t % 2 == 0)
+        assert N.last_kernel().endswith("MarlCore+ring>") if fused else N.last_kernel() == "k_step<%d,RING>" % V, N.last_kernel()
+    assert buf.mem_cntr == buf2.mem_cntr == T * E and env._steps == env2._steps == T
+    for k in ("data_buf", "reward", "obs", "metrics", "mec_q", "gain", "rate", "data_t", "data_p", "over_power"):
+        assert torch.equal(env.tensors[k], env2.tensors[k]), k
+    for k in buf._ARRAYS:
+        assert torch.equal(getattr(buf, k), getattr(buf2, k)), k
+    # shapes without a fused-gains form are refused, not silently run without the store
+    if fused:
+        env3 = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, 22, 3, n_envs=E,
+                          device=DEV, seed=21)
+        env3.make_new_game(); env3.compute_parms()
+        bad = env3.bind_step_store(buf2, pw2, partner, ng, pr2, None, fused=True)
+        with pytest.raises(N.RisVecError):
+            bad()
