@@ -174,8 +174,8 @@ typedef struct RisVecState {
        when non-NULL, read by risvec_step_fused with RISVEC_STEP_STEER */
     double *z_r;            /* [E,V]   c128 (may be NULL)                                 */
     /* Candidate index of every theta element as the last sweep left it (0..7 = exp(j 2 pi k / 8), ENV:169, 213;
-       8 = the integer 0 of ENV:211, 220), one byte each, row-major [E][8*ceil(M/8)] (rows padded to whole 8-element
-       tiles); written by every control_bit = 3 sweep, read with RISVEC_BCD_REUSE_IDX / RISVEC_STEP_THETA_BY_INDEX
+       8 = the integer 0 of ENV:211, 220), one byte each, row-major [E][32*ceil(M/32)] (rows padded to a multiple of
+       32 bytes); written by every control_bit = 3 sweep, read with RISVEC_BCD_REUSE_IDX / RISVEC_STEP_THETA_BY_INDEX
        (may be NULL) */
     uint8_t *theta_idx;
 } RisVecState;

@@ -247,8 +247,8 @@ constexpr int kTRow = kSweepBlk + 2;                        // LDS row stride of
 
 // theta_idx: the candidate index of every theta element as the last 2^b = 8 sweep left it (8 = the integer 0 of
 // ENV:211, 220), one byte per element, ROW-MAJOR [E][8 ceil(M / 8)] (round 3: the fused step kernel reads it along m
-// when theta is kept by index, and a sweep reads / writes one 8-byte word per env and tile -- the 64 rows of a
-// wavefront stay in L1 from tile to tile).
+// when theta is kept by index).  Rows are padded to a multiple of 32 bytes: the pair sweep moves the indices of
+// FOUR tiles per request.
 
 template <int NC>
 __global__ void __launch_bounds__(kWave)
@@ -401,7 +401,7 @@ k_bcd_sweep(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
                 lo |= (unsigned)(ko[j] < 0 ? 8 : ko[j]) << (8 * j);
                 hi |= (unsigned)(ko[j + 4] < 0 ? 8 : ko[j + 4]) << (8 * j);
             }
-            *reinterpret_cast<uint2*>(theta_idx + (e * n_blk + kb) * 8) = make_uint2(lo, hi);
+            *reinterpret_cast<uint2*>(theta_idx + e * theta_idx_stride(M) + kb * 8) = make_uint2(lo, hi);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -459,7 +459,7 @@ struct PairOut { float cr, ci; int k, pad; };               // 16 bytes
 
 __device__ __forceinline__ int dpp_x1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); }
 
-template <bool PAD, bool WTH = true, bool STAMP = false, int RING = 4>
+template <bool PAD, bool WTH = true, bool STAMP = false>
 __global__ void __launch_bounds__(kWave)
 k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ theta,
                   int32_t* __restrict__ idx_out, double* __restrict__ s_sum, int reuse_s,
@@ -493,9 +493,13 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
     const long long e = live ? e0 + ei : d.E - 1;
     const long long slab = blockIdx.x >> 1;
     const int sl = (blockIdx.x & 1) * HALF + ei;            // this env's lane in its 64-env slab
-    const double2* __restrict__ cg = reinterpret_cast<const double2*>(c_col) + slab * M * kWave + sl;
+    // c_col is addressed as (wave-uniform slab base + coordinate row, in SGPRs) + (this lane's 32-bit byte offset):
+    // the loads take the scalar-base form and a tile's eight addresses cost two scalar adds, not eight 64-bit vector adds
+    const char* __restrict__ cgs = reinterpret_cast<const char*>(c_col) + slab * M * (kWave * 16LL);
+    const unsigned cgl = (unsigned)sl * 16u;
     const int n_blk = (M + kSweepBlk - 1) / kSweepBlk;
-    uint8_t* __restrict__ ig = theta_idx + e * (long long)n_blk * 8;        // this env's row of candidate indices
+    uint8_t* __restrict__ ig = theta_idx + e * (long long)theta_idx_stride(M);     // this env's row of candidate indices
+    constexpr int RING = 4;                                 // tile images in flight = tiles per index group
     const unsigned sgn = (unsigned)hb << 31;
     const PairOld* __restrict__ told = s_old[hb];
     const PairOut* __restrict__ tout = s_out[hb];
@@ -504,12 +508,15 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
         double2 c[kSweepBlk];
         uint2 k;
     };
-    auto fetch = [&](Tile& t, int kb) {
+    auto fetch = [&](Tile& t, int kb, bool with_idx = false) {
         const int kbc = kb < n_blk ? kb : n_blk - 1;           // past the end: harmless re-read of the last tile
+        const char* __restrict__ row = cgs + (long long)kbc * (kSweepBlk * kWave * 16);     // uniform
 #pragma unroll
-        for (int j = 0; j < kSweepBlk; ++j)
-            t.c[j] = cg[(long long)(PAD ? min(kbc * kSweepBlk + j, M - 1) : kbc * kSweepBlk + j) * kWave];
-        t.k = *reinterpret_cast<const uint2*>(ig + kbc * 8);
+        for (int j = 0; j < kSweepBlk; ++j) {
+            const int jj = PAD ? min(kbc * kSweepBlk + j, M - 1) - kbc * kSweepBlk : j;
+            t.c[j] = *reinterpret_cast<const double2*>(row + jj * (kWave * 16) + cgl);
+        }
+        if (with_idx) t.k = *reinterpret_cast<const uint2*>(ig + kbc * 8);      // (the chain takes its indices by groups of 4 tiles)
     };
     auto old_of = [&](const Tile& t, int j) -> PairOld { return told[((j < 4 ? t.k.x : t.k.y) >> (8 * (j & 3))) & 15u]; };
     auto flip = [&](double cy) { return __hiloint2double(__double2hiint(cy) ^ (int)sgn, __double2loint(cy)); };
@@ -522,7 +529,7 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
         double T = 0.0;
         Tile ta, tb;
         auto sum_tile = [&](int kb, const Tile& cur, Tile& nxt) {
-            fetch(nxt, kb + 1);
+            fetch(nxt, kb + 1, true);
 #pragma unroll
             for (int j = 0; j < kSweepBlk; j += 2) {
                 const bool ok0 = !PAD || kb * kSweepBlk + j < M, ok1 = !PAD || kb * kSweepBlk + j + 1 < M;
@@ -531,7 +538,7 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
                 T = fma(b2.p1, cur.c[j + 1].x, T); T = fma(b2.p2, flip(cur.c[j + 1].y), T);
             }
         };
-        fetch(ta, 0);
+        fetch(ta, 0, true);
         for (int kb = 0; kb < n_blk; kb += 2) {
             sum_tile(kb, ta, tb);
             if (kb + 1 < n_blk) sum_tile(kb + 1, tb, ta);
@@ -546,7 +553,7 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
     float4* __restrict__ trow4 = reinterpret_cast<float4*>(theta + e * (long long)M * 2) + 2 * hb;
     float2* __restrict__ trow2 = reinterpret_cast<float2*>(theta + e * (long long)M * 2) + 4 * hb;
     const double tn = 0.41421356237309503;                  // tan(pi/8)
-    auto chain_tile = [&](int kb, Tile& cur, Tile& nxt, int ahead) {
+    auto chain_tile = [&](int kb, Tile& cur, Tile& nxt, int ahead) -> unsigned {
         fetch(nxt, kb + ahead);
         if constexpr (STAMP) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -659,7 +666,6 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
                         if (kb * kSweepBlk + 4 * hb + s < M) trow2[kb * kSweepBlk + s] = out[s];
                 }
             }
-            *reinterpret_cast<unsigned*>(ig + kb * 8 + 4 * hb) = kw;
         }
         if (!STAMP && idx_out && live) {
 #pragma unroll
@@ -670,6 +676,7 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
             }
         }
         if constexpr (STAMP) t_epi += (long long)__builtin_amdgcn_s_memtime();
+        return kw;
     };
     {
         // a ring of RING tile images, RING - 1 tiles ahead of the chain: the requests a wavefront keeps in flight
@@ -677,10 +684,33 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
         Tile ring[RING];
 #pragma unroll
         for (int r = 0; r + 1 < RING; ++r) fetch(ring[r], r);
+        // The candidate indices move by GROUPS of four tiles (32 bytes of the env's row): one 2 x 16-byte read a group
+        // ahead, and ONE 16-byte store per lane per group -- the even lane the first two tiles' words, the odd lane the
+        // last two, halves swapped through DPP.  (A 4-byte store per lane and tile touched 32 cache lines per
+        // instruction; loads and stores retire in order, so the tiles' c requests queued behind those stores:
+        // +30 cycles per coordinate in the s_memtime stamps.)
+        const int n_grp = (n_blk + 3) / 4;
+        uint4 ic[2], inx[2];
+        auto fetch_idx = [&](uint4 (&dst)[2], int g) {
+            const uint4* __restrict__ p = reinterpret_cast<const uint4*>(ig + (g < n_grp ? g : n_grp - 1) * 32);
+            dst[0] = p[0]; dst[1] = p[1];
+        };
+        fetch_idx(ic, 0);
         for (int kb = 0; kb < n_blk; kb += RING) {
+            fetch_idx(inx, kb / 4 + 1);
+            unsigned kwq[4] = {0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
 #pragma unroll
-            for (int r = 0; r < RING; ++r)
-                if (kb + r < n_blk) chain_tile(kb + r, ring[r], ring[(r + RING - 1) % RING], RING - 1);
+            for (int r = 0; r < RING; ++r) {
+                if (kb + r < n_blk) {
+                    const uint4 w = ic[r >> 1];
+                    ring[r].k = (r & 1) ? make_uint2(w.z, w.w) : make_uint2(w.x, w.y);
+                    kwq[r] = chain_tile(kb + r, ring[r], ring[(r + RING - 1) % RING], RING - 1);
+                }
+            }
+            const unsigned r0 = (unsigned)dpp_x1((int)(hb ? kwq[0] : kwq[2])), r1 = (unsigned)dpp_x1((int)(hb ? kwq[1] : kwq[3]));
+            const uint4 wq = hb ? make_uint4(r0, kwq[2], r1, kwq[3]) : make_uint4(kwq[0], r0, kwq[1], r1);
+            if (live) *reinterpret_cast<uint4*>(ig + (kb / 4) * 32 + 16 * hb) = wq;
+            ic[0] = inx[0]; ic[1] = inx[1];
         }
     }
     if (live && s_sum) s_sum[e * 2 + hb] = S;
@@ -738,7 +768,7 @@ static hipError_t launch_sweep_nc(const RisVecState& s, int32_t* idx_out, bool r
 // complex64 tensor after sweeps that kept theta by index.  One lane per 4 elements: 4 bytes in, 32 bytes out.
 __global__ void __launch_bounds__(kBlock)
 k_theta_from_index(Dims d, const uint8_t* __restrict__ theta_idx, float* __restrict__ theta) {
-    const int MK = (d.M + 7) / 8 * 8, q = MK / 4;
+    const int MK = theta_idx_stride(d.M), q = MK / 4;
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (long long)d.E * q) return;
     const long long e = t / q;
@@ -794,13 +824,10 @@ hipError_t launch_bcd(const RisVecState& s, const RisVecParams&, int32_t* idx_ou
             return hipGetLastError();
         }
 #endif
-        static const int ring = [] { const char* e = std::getenv("RISVEC_SWEEP_RING"); return e ? std::atoi(e) : 4; }();
-#define RISVEC_PAIR(PAD, WTH, R) hipLaunchKernelGGL((k_bcd_sweep8_pair<PAD, WTH, false, R>), dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, \
-                                                    s.theta, idx_out, s.s_sum, rs, s.theta_idx)
-#define RISVEC_PAIR_R(PAD, WTH) do { if (ring == 8) RISVEC_PAIR(PAD, WTH, 8); else if (ring == 6) RISVEC_PAIR(PAD, WTH, 6); else RISVEC_PAIR(PAD, WTH, 4); } while (0)
-        if (pad) { if (write_theta) RISVEC_PAIR_R(true, true); else RISVEC_PAIR_R(true, false); }
-        else { if (write_theta) RISVEC_PAIR_R(false, true); else RISVEC_PAIR_R(false, false); }
-#undef RISVEC_PAIR_R
+#define RISVEC_PAIR(PAD, WTH) hipLaunchKernelGGL((k_bcd_sweep8_pair<PAD, WTH>), dim3(gp), dim3(kWave), 0, st, dims_of(s), s.c_col, \
+                                                 s.theta, idx_out, s.s_sum, rs, s.theta_idx)
+        if (pad) { if (write_theta) RISVEC_PAIR(true, true); else RISVEC_PAIR(true, false); }
+        else { if (write_theta) RISVEC_PAIR(false, true); else RISVEC_PAIR(false, false); }
 #undef RISVEC_PAIR
         note_kernel("k_bcd_sweep8_pair<%s,%s>", pad ? "PAD" : "M%8=0", write_theta ? "theta written" : "theta by index");
         return hipGetLastError();

@@ -86,8 +86,9 @@ hipError_t launch_episode_accumulate(int E, int V, const float* metrics, const f
 hipError_t launch_episode_summary(int E, int V, int n_steps, const double* acc, const float* metrics, double* per_env,
                                   double* partial, double* summary, hipStream_t st);
 
-// bytes per env row of state.theta_idx: the candidate index of every theta element, padded to whole 8-element tiles
-inline int theta_idx_stride(int n_ris) { return (n_ris + 7) / 8 * 8; }
+// bytes per env row of state.theta_idx: the candidate index of every theta element, padded to a multiple of 32
+// (four 8-element tiles: the pair sweep reads and writes the indices of four tiles per request)
+__host__ __device__ inline int theta_idx_stride(int n_ris) { return (n_ris + 31) / 32 * 32; }
 hipError_t launch_theta_from_index(const RisVecState& s, hipStream_t st);
 
 // risvec_last_kernel(): the launchers of the step path and the BCD sweep name the kernel they dispatched (per thread)

@@ -150,8 +150,8 @@ class VecEnviron(ParamAttrs):
         t["c_col"] = z((E + 63) // 64, M, 64, 2, dt=torch.float64)
         t["s_sum"] = z(E, 2, dt=torch.float64)         # sum_m theta_m c_m left by the last sweep
         t["z_r"] = z(E, V, 2, dt=torch.float64)        # steering base exp(-j pi angle) per vehicle: h_r[e,v,m] = z^m
-        # candidate index of every theta element as the last BCD sweep left it: [E, 8 ceil(M/8)] bytes
-        t["theta_idx"] = z(E, (M + 7) // 8 * 8, dt=torch.uint8)
+        # candidate index of every theta element as the last BCD sweep left it: [E, 32 ceil(M/32)] bytes
+        t["theta_idx"] = z(E, (M + 31) // 32 * 32, dt=torch.uint8)
         s = N.RisVecState()
         s.abi_version = N.ABI_VERSION
         s.struct_bytes = C.sizeof(N.RisVecState)
