@@ -62,7 +62,18 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int gl = lane % G, gv = lane / G;
-    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    if constexpr (!MULTI) {
+        // A stream a little larger than the Infinity Cache (1 ... 1.29 x) is read with the default cache policy and walked
+        // in ALTERNATING directions from step to step (A.ping: the launcher's step parity): the lines the previous
+        // launch touched last -- the ones still cached -- are the first this launch asks for, where a same-direction
+        // walk of an LRU-like cache hits nothing.  Which wavefront serves which env changes nothing in the results.
+        // Measured (tools/gpu_pingpong.sh, profiles/r03q_pingpong_band.txt, r03p_*; h_r + theta per step at E x 8 x 64, us
+        // per step round-2 dispatch / this): 283 MB 49.9 / 48.6, 302 MB 59.1 / 53.7, 340 MB 70.2 / 62.0, 377 MB 70.1 / 70.6,
+        // 528 MB 100.2 / 101.5, 1.2 GB 226 / 236.
+        const int n_waves = (d.E + EPWT - 1) / EPWT;
+        if (A.ping && wid < n_waves) wid = n_waves - 1 - wid;
+    }
     const int e0 = wid * EPWT;
     unsigned long long ts[5] = {0, 0, 0, 0, 0};
     if constexpr (STAMP) ts[0] = __builtin_amdgcn_s_memrealtime();
@@ -250,18 +261,32 @@ static int lat_epwt(int n_envs) {
     return e;
 }
 
+static long long stream_bytes_of(const RisVecState& s) { return (long long)s.n_envs * (8LL * s.n_veh * s.n_ris + 8LL * s.n_ris); }
+
+// RISVEC_LAT_PINGPONG: 0 never / 1 always (tests) / 2 (default) when the stream lies in (1, 1.29] x the Infinity Cache
+static bool alternate_walk(const RisVecState& s) {
+    static const int mode = env_int("RISVEC_LAT_PINGPONG", 2);
+    if (mode != 2) return mode == 1;
+    const long long b = stream_bytes_of(s);
+    return b > tuning().ic_bytes && b <= tuning().lat_nt_from;
+}
+
 template <class S, int EPWT, bool MULTI, bool NT, bool TK>
-static hipError_t launch_one(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
+static hipError_t launch_one(const RisVecState& s, const RisVecParams& p, const StepArgs& a0, int n_steps,
                              const RisVecTraj& tj, hipStream_t st) {
     const long long waves = ((long long)s.n_envs + EPWT - 1) / EPWT;
     const unsigned grid = (unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave));
+    StepArgs a = a0;
+    const bool alt = !MULTI && !NT && alternate_walk(s);
+    a.ping = alt ? (int)(a.counter & 1u) : 0;
     hipLaunchKernelGGL((k_step_fused_lat<S, EPWT, MULTI, false, NT, TK>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a,
                        n_steps, tj);
+    const char* pol = NT ? ",NT" : (alt ? ",ALT" : "");        // non-temporal loads / default policy + alternating walk
     if (S::FIXED)
-        note_kernel("k_step_fused_lat<%d,%d,%d%s%s%s>", S::V, S::MC, EPWT, MULTI ? ",MULTI" : "", NT ? ",NT" : "", TK ? ",TK" : "");
+        note_kernel("k_step_fused_lat<%d,%d,%d%s%s%s>", S::V, S::MC, EPWT, MULTI ? ",MULTI" : "", pol, TK ? ",TK" : "");
     else
         note_kernel("k_step_fused_lat<%d,M=%d(G=%d,NIT=%d),%d%s%s%s>", S::V, s.n_ris, S::G, S::NIT, EPWT, MULTI ? ",MULTI" : "",
-                    NT ? ",NT" : "", TK ? ",TK" : "");
+                    pol, TK ? ",TK" : "");
     return hipGetLastError();
 }
 
@@ -338,9 +363,11 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
     if (!step_fused_lat_covers(V, M)) return hipErrorNotSupported;
     static const long long forced_limit = [] { const char* e = std::getenv("RISVEC_LAT_MAX_ENVS"); return e ? std::atoll(e) : -1LL; }();
     static const int nt_mode = env_int("RISVEC_LAT_NT", 2);
-    const long long stream_bytes = (long long)s.n_envs * (8LL * V * M + 8LL * M);
+    const long long stream_bytes = stream_bytes_of(s);
     const bool off = forced_limit == 0;                        // the family is switched off where a pipeline exists
     const bool nt = !off && (nt_mode == 1 || (nt_mode == 2 && stream_bytes > tuning().lat_nt_from));
+    // between the cache size and lat_nt_from: this kernel with the default policy and the alternating walk (launch_one)
+    const bool band = !off && !nt && nt_mode != 1 && alternate_walk(s) && stream_bytes > tuning().ic_bytes;
     const int epwt = lat_epwt(s.n_envs);
     if (epwt <= 0) return hipErrorNotSupported;
     // wavefronts per CU (of 4 envs) up to which this kernel beats the shape's software pipeline
@@ -361,11 +388,11 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
     }
 #endif
     if (V == 8 && M == 64) {
-        if (!nt && !a.theta_k && !below(24)) return hipErrorNotSupported;
+        if (!nt && !band && !a.theta_k && !below(24)) return hipErrorNotSupported;
         return launch_single<S8x64, 1, 4, true>(s, p, a, epwt, nt, st);
     }
     if (V == 4 && M == 16) {
-        if (!nt && !below(24)) return hipErrorNotSupported;
+        if (!nt && !band && !below(24)) return hipErrorNotSupported;
         return launch_single<S4x16, 1, 4, false>(s, p, a, epwt, nt, st);
     }
     if (V == 16 && M == 64) {

@@ -94,7 +94,10 @@ struct MarlCore {
 //   pipe_nt_from   h_r + theta bytes of one step from which the software pipeline reads them with the non-temporal
 //                  hint = 1.055 x ic_bytes (measured crossover 263 ... 288 MiB on a 256 MiB cache: below it last
 //                  step's lines are still resident and the hint throws that away)
-//   lat_nt_from    the same for the latency-shaped kernel = 1.29 x ic_bytes (measured crossover 294 ... 368 MiB)
+//   lat_nt_from    from here the latency-shaped kernel streams with the non-temporal hint = 1.29 x ic_bytes (measured
+//                  crossover 294 ... 368 MiB); between ic_bytes and this it reads with the default policy and walks the
+//                  envs in alternating directions from step to step (round 3: 3-12 % faster than the hint in that band,
+//                  equal at 1.4 x, 4 % slower at 5 x)
 // The RISVEC_* environment switches remain as overrides for same-box A/Bs and the bit-identity tests.
 // ---------------------------------------------------------------------------
 struct Tuning {

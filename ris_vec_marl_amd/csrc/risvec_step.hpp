@@ -71,6 +71,7 @@ struct StepArgs {
     // (state.theta_idx); nullptr = read the complex64 theta
     const uint8_t* theta_k;
     int theta_k_stride;
+    int ping;                       // non-temporal kernels: walk the envs in reverse this launch (step parity)
     StepRing ring;                  // used by the RING instances of the kernels only
 };
 
@@ -689,7 +690,7 @@ inline StepArgs make_step_args(const RisVecState& s, const float* action, const 
     a.rate = s.rate; a.data_t = s.data_t; a.data_p = s.data_p; a.reward = s.reward;
     a.over_power = s.over_power; a.obs = s.obs; a.metrics = s.metrics; a.power_w = s.power_w;
     a.seed = seed; a.counter = counter; a.flags = flags;
-    a.theta_k = nullptr; a.theta_k_stride = 0;
+    a.theta_k = nullptr; a.theta_k_stride = 0; a.ping = 0;
     a.ring = StepRing{};
     return a;
 }

@@ -551,6 +551,16 @@ def test_non_temporal_variants_are_bit_identical(E, V, M):
         lat = np.load(dst)
         for k in outs[0].files:
             assert np.array_equal(outs[0][k], lat[k]), k
+        # and the form taken between 1 x and 1.29 x the Infinity Cache: default cache policy, the envs walked in alternating
+        # directions from step to step (RISVEC_LAT_PINGPONG=1 forces it at this size)
+        e = dict(os.environ, RISVEC_LAT_PINGPONG="1", RISVEC_PIPE_NT="0", RISVEC_COLSUM_NT="0")
+        dst = os.path.join(tmp, "lat_alt.npz")
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), dst], env=e, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        alt = np.load(dst)
+        for k in outs[0].files:
+            assert np.array_equal(outs[0][k], alt[k]), k
 
 
 # ---------------------------------------------------------------------------- run-time-M members of the fused family
@@ -783,6 +793,21 @@ def test_full_size_dispatch_beyond_the_infinity_cache():
             assert np.array_equal(mine[k], other[k]), k
     for lo, hi in ((0, E // 2), (E // 2, E)):
         half = _big_rollout(hi - lo, V, M, lo=lo)
+        for k in mine:
+            assert np.array_equal(half[k], mine[k][lo:hi]), k
+
+
+def test_full_size_dispatch_just_beyond_the_infinity_cache():
+    """65 536 x 8 x 64 (302 MB of h_r + theta per step, 1.13 x the Infinity Cache): k_step_fused_lat<8,64,4,ALT> -- default cache policy,
+    envs walked in alternating directions from step to step -- must equal its two halves (32 768 envs each: the software
+    pipeline) bit for bit over three steps (both walking directions)."""
+    from ris_vec_marl_amd import _native as N
+    E, V, M = 65536, 8, 64
+    mine = _big_rollout(E, V, M, steps=3)
+    assert N.last_kernel() == "k_step_fused_lat<8,64,4,ALT>", N.last_kernel()
+    for lo, hi in ((0, E // 2), (E // 2, E)):
+        half = _big_rollout(hi - lo, V, M, lo=lo, steps=3)
+        assert N.last_kernel().startswith("k_step_fused_pipe<8,64,2,MarlCore"), N.last_kernel()
         for k in mine:
             assert np.array_equal(half[k], mine[k][lo:hi]), k
 
