@@ -420,7 +420,7 @@ int risvec_noma_begin_episode(const RisVecNomaState *ns, risvec_stream_t stream)
 /* Channel-refresh step (TRAIN:1319-1343): tau = quantile q_now of |g_strong - g_weak| in dB
  * (TRAIN:842-855) -> ns->tau; with K_now >= 1 also the N x N mask (TRAIN:134-156) -> ns->mask.
  * gain [E,N] float32 linear; gdb15 [E,N] float64 = 10 log10(max(g, 1e-15)) or NULL (computed on
- * the device; pass it to reproduce a host's log10 bit for bit -- see DESIGN.md, f2). */
+ * the device; pass it to reproduce a host's log10 bit for bit -- see EXPERIMENTS.md, section 8 f2). */
 int risvec_noma_mask(const RisVecNomaState *ns, const float *gain, const double *gdb15, double q_now,
                      int32_t K_now, risvec_stream_t stream);
 

@@ -16,7 +16,7 @@
 // In a solve the N x N matrices (N <= 16) live in LDS with the entries dealt round-robin to
 // the lanes; every decision the reference takes by comparing float64 numbers is taken by comparing
 // float64 numbers formed in the same association order (fp contraction is off for the whole file:
-// the matcher's exact ties are decided by last-bit rounding).
+// the matcher's exact ties are decided by last-bit rounding, see EXPERIMENTS.md, section 8 f2).
 //   * quantiles: no sort -- each lane ranks its own entries against all (LDS broadcast reads) and
 //     the two order statistics NumPy's linear method interpolates are picked by rank;
 //   * matching: the reference's memoised recursion on the lowest unused user x, evaluated bottom-up

@@ -251,7 +251,7 @@ static int env_int(const char* name, int dflt) {
     return s ? std::atoi(s) : dflt;
 }
 
-// envs per wavefront: as many (<= 4) as keep >= 8 wavefronts per CU in flight (measured: DESIGN.md section 6)
+// envs per wavefront: as many (<= 4) as keep >= 8 wavefronts per CU in flight (measured: EXPERIMENTS.md, rounds 1-2 section 6)
 static int lat_epwt(int n_envs) {
     static const int forced = env_int("RISVEC_LAT_EPW", -1);   // A/B switch; 0 disables the latency-shaped single-step kernel
     if (forced >= 0) return forced;
