@@ -578,11 +578,15 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
             const double w = fma(r_o, cys, r * cx);
             const double w_o = xchg<1>(w);
             // masks instead of booleans: every select below is one v_bfi / v_and_or, no scalar-mask logic on the chain
-            const unsigned am = fabs(w_o) <= tn * fabs(w) ? ~0u : 0u;          // the winner lies along this lane's axis
+            // |w_other| <= tan(pi/8) |w_self|  <=>  |w_other| - tan(pi/8) |w_self| < 0 (equality only at w = 0: replayed):
+            // ONE fused float64 instruction and an arithmetic shift of its sign instead of multiply + compare + select
+            unsigned am = (unsigned)(__double2hiint(fma(-tn, fabs(w), fabs(w_o))) >> 31);   // winner along this lane's axis
+            asm("" : "+v"(am));      // opaque: or the compiler turns the bit operations below back into a 64-bit compare + selects
             const unsigned bm = (unsigned)dpp_x1((int)am);                      // ... along the other lane's axis
             const unsigned whi = (unsigned)__double2hiint(w);
             const unsigned nlo = ~(am | bm) & R_LO;
-            const unsigned mag = (am & ONE_HI) | (~am & (~bm & R_HI));          // 1 | 0 | r  (both masks set: q = 0, replayed)
+            // 1 | 0 | r as three-input bit operations (both masks set: q = 0, replayed)
+            const unsigned mag = ((am & (ONE_HI ^ R_HI)) ^ R_HI) & ~(bm & ~am);
             const unsigned nhi = (whi & 0x80000000u) | mag;                     // a signed zero is as good as zero here
             const double n_s = __hiloint2double((int)nhi, (int)nlo);
             const double n_o = __hiloint2double(dpp_x1((int)nhi), (int)nlo);
