@@ -27,6 +27,7 @@
 //                 are transposed through LDS (see the kernel).  An earlier form that staged c for
 //                 whole envs in LDS was capped by LDS capacity at 38 envs per CU in flight.
 #include <cstdlib>
+#include <type_traits>
 
 #include "risvec_pipe.hpp"
 
@@ -508,7 +509,7 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
         double2 c[kSweepBlk];
         uint2 k;
     };
-    auto fetch = [&](Tile& t, int kb, bool with_idx = false) {
+    auto fetch = [&](Tile& t, int kb, bool with_idx = false) __attribute__((always_inline)) {
         const int kbc = kb < n_blk ? kb : n_blk - 1;           // past the end: harmless re-read of the last tile
         const char* __restrict__ row = cgs + (long long)kbc * (kSweepBlk * kWave * 16);     // uniform
 #pragma unroll
@@ -553,7 +554,7 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
     float4* __restrict__ trow4 = reinterpret_cast<float4*>(theta + e * (long long)M * 2) + 2 * hb;
     float2* __restrict__ trow2 = reinterpret_cast<float2*>(theta + e * (long long)M * 2) + 4 * hb;
     const double tn = 0.41421356237309503;                  // tan(pi/8)
-    auto chain_tile = [&](int kb, Tile& cur, Tile& nxt, int ahead) -> unsigned {
+    auto chain_tile = [&](int kb, Tile& cur, Tile& nxt, int ahead) __attribute__((always_inline)) -> unsigned {
         fetch(nxt, kb + ahead);
         if constexpr (STAMP) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -601,7 +602,7 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
         // epilogue: this lane's four coordinates (4 hb + s): code -> float32 image and index of the winner
         float2 out[4];
         unsigned kw = 0;
-        if (!__any(zmin == 0.f)) {
+        if (__builtin_expect(!__any(zmin == 0.f), 1)) {       // (the fall-through: the replay below practically never runs)
             const unsigned acc_o = (unsigned)dpp_x1((int)acc);
             const unsigned fs = (acc >> (hb ? 0 : 8)) & 0xFFu, fo = (acc_o >> (hb ? 0 : 8)) & 0xFFu;
 #pragma unroll
@@ -671,12 +672,16 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
                 }
             }
         }
-        if (!STAMP && idx_out && live) {
+        // (tests and `return_idx` only: one wave-uniform, not-taken branch on the production path -- as per-lane
+        // conditions these four stores were four taken branches, i.e. four instruction-fetch restarts, per tile)
+        if (!STAMP && __builtin_expect(idx_out != nullptr, 0)) {
+            if (live) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int m = kb * kSweepBlk + 4 * hb + s;
-                const unsigned kn = (kw >> (8 * s)) & 15u;
-                if (m < M) idx_out[e * M + m] = kn == 8u ? -1 : (int)kn;
+                for (int s = 0; s < 4; ++s) {
+                    const int m = kb * kSweepBlk + 4 * hb + s;
+                    const unsigned kn = (kw >> (8 * s)) & 15u;
+                    if (!PAD || m < M) idx_out[e * M + m] = kn == 8u ? -1 : (int)kn;
+                }
             }
         }
         if constexpr (STAMP) t_epi += (long long)__builtin_amdgcn_s_memtime();
@@ -695,17 +700,20 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
         // +30 cycles per coordinate in the s_memtime stamps.)
         const int n_grp = (n_blk + 3) / 4;
         uint4 ic[2], inx[2];
-        auto fetch_idx = [&](uint4 (&dst)[2], int g) {
+        auto fetch_idx = [&](uint4 (&dst)[2], int g) __attribute__((always_inline)) {
             const uint4* __restrict__ p = reinterpret_cast<const uint4*>(ig + (g < n_grp ? g : n_grp - 1) * 32);
             dst[0] = p[0]; dst[1] = p[1];
         };
         fetch_idx(ic, 0);
-        for (int kb = 0; kb < n_blk; kb += RING) {
+        // FULL groups run straight through (no per-tile test: each was a taken branch out and back); a last partial group
+        // (n_blk % 4 != 0) tests every tile
+        auto do_group = [&](int kb, auto full_tag) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
             fetch_idx(inx, kb / 4 + 1);
             unsigned kwq[4] = {0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
 #pragma unroll
             for (int r = 0; r < RING; ++r) {
-                if (kb + r < n_blk) {
+                if (FULL || kb + r < n_blk) {
                     const uint4 w = ic[r >> 1];
                     ring[r].k = (r & 1) ? make_uint2(w.z, w.w) : make_uint2(w.x, w.y);
                     kwq[r] = chain_tile(kb + r, ring[r], ring[(r + RING - 1) % RING], RING - 1);
@@ -715,7 +723,10 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
             const uint4 wq = hb ? make_uint4(r0, kwq[2], r1, kwq[3]) : make_uint4(kwq[0], r0, kwq[1], r1);
             if (live) *reinterpret_cast<uint4*>(ig + (kb / 4) * 32 + 16 * hb) = wq;
             ic[0] = inx[0]; ic[1] = inx[1];
-        }
+        };
+        int kb = 0;
+        for (; kb + RING <= n_blk; kb += RING) do_group(kb, std::true_type{});
+        if (kb < n_blk) do_group(kb, std::false_type{});
     }
     if (live && s_sum) s_sum[e * 2 + hb] = S;
     if constexpr (STAMP) {
