@@ -41,7 +41,7 @@ for _ in range(reps):
     env.Random_phase()
     env.get_next_phase(phase)
     env.optimize_phase_shift()         # k_bcd_sweep: the generic sweep (theta set by hand: indices unknown), column sums cached
-    env.optimize_phase_shift()         # k_bcd_sweep8_idx: the indexed sweep (indices left by the previous one, cached sum)
+    env.optimize_phase_shift()         # k_bcd_sweep8_pair: the indexed sweep (indices left by the previous one, cached sum)
     env.update_channel_gains()         # k_gain
     env.data_rate(pw, partner, ng)
     env.step(action, partner, ng, None, fused=False, power_w=False)
@@ -75,7 +75,7 @@ torch.cuda.synchronize()
 B = dict(
     k_reset=E * V * (16 + 4 + 4 + 4), k_mobility=E * V * (16 + 4 + 4 + 16 + 4), k_geometry=E * V * (16 + 12 + 8 * M),
     k_colsum=E * (8 * V * M + 16 * M), k_random_phase=E * 8 * M, k_set_phase=E * 12 * M,
-    k_bcd_sweep=E * (2 * 16 * M + 2 * 8 * M + 8 * M), k_bcd_sweep8_idx=E * (16 * M + 2 * M + 8 * M + 32),
+    k_bcd_sweep=E * (2 * 16 * M + 2 * 8 * M + 8 * M), k_bcd_sweep8_pair=E * (16 * M + 2 * M + 8 * M + 32), k_theta_from_index=E * 9 * M,
     k_colsum_slab=E * (8 * V * M + 16 * M),
     k_step_fused_lat=E * (8 * V * M + 8 * M + 16 * (8 * V + 24 * V + 64) + 40 * V + 8), k_gain=E * (8 * V * M + 8 * M + 8 * V),
     k_data_rate=E * 16 * V + 4 * E, k_step=E * (60 * V + 68), k_step_multi=E * 16 * (8 * V + 24 * V + 64) + E * (60 * V + 68), k_step_fused=E * (8 * V * M + 8 * M + 64 * V + 68),
