@@ -1,5 +1,5 @@
 #!/bin/bash
-TAG=${1:-sw3}
+TAG=${1:-sweep}
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 timeout -k 10 1000 python -m pytest tests -m gpu -q -x -p no:cacheprovider > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_$TAG.log
 timeout -k 10 200 python tools/sweep_stamps.py 32768 16 256 > $OUT/sweep_stamps_$TAG.json 2>$OUT/sweep_stamps_$TAG.err; cat $OUT/sweep_stamps_$TAG.json
