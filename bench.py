@@ -524,7 +524,8 @@ def run_leg(name, E, V, M, mode, device, rank, world, steps, warmup, gather_ever
         out["gather_ok"] = case.gather_ok
         out["env_steps_per_s"] = None
     case.close()
-    if yardstick and rank == 0 and world == 1 and not STUB:
+    # (not for T-step launches: a single-launch reader of 1.7 MB measures the launch floor the T-step form exists to avoid)
+    if yardstick and rank == 0 and world == 1 and not STUB and multi <= 1:
         # the best pure float4 reader of THE SAME NUMBER OF BYTES on this device, in this process
         y = yardstick_read(int(per_env * E), device)
         if y:

@@ -91,3 +91,36 @@ extern "C" int membench_read2(const void* src, long long n, void* sink, int bloc
 #undef RB_CASE
     return -1;
 }
+
+// ---- round 3 probe: which load cache-policy bits keep a SMALL re-read buffer resident in the Infinity Cache while a
+// LARGE stream goes past it?  Raw buffer loads so that the policy is an operand (aux: 1 = sc0, 2 = nt, 16 = sc1).
+template <int AUX>
+__global__ void __launch_bounds__(256)
+k_read_aux(const float4* __restrict__ src, long long n, float* __restrict__ sink) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const long long per = (n + gridDim.x - 1) / gridDim.x;                 // float4 per workgroup (contiguous chunk)
+    const long long base = (long long)blockIdx.x * per;
+    long long cnt = n - base < per ? n - base : per;
+    if (cnt < 0) cnt = 0;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(src + base), 0, (int)(cnt * 16), 0x00027000);
+    float a = 0.f, b = 0.f, c = 0.f, d2 = 0.f;
+    for (long long i = threadIdx.x; i < cnt; i += 8 * 256) {
+        v4u x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((i + k * 256) * 16), 0, AUX);   // out of range: 0
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a += __builtin_bit_cast(float, x[k].x); b += __builtin_bit_cast(float, x[k].y);
+            c += __builtin_bit_cast(float, x[k].z); d2 += __builtin_bit_cast(float, x[k].w);
+        }
+    }
+    sink[(long long)blockIdx.x * 256 + threadIdx.x] = a + b + c + d2;
+}
+
+extern "C" int membench_read_aux(const void* src, long long n_float4, void* sink, int blocks, int aux, void* stream) {
+    const float4* s = (const float4*)src; float* k = (float*)sink; hipStream_t st = (hipStream_t)stream;
+#define RA(A) case A: hipLaunchKernelGGL((k_read_aux<A>), dim3(blocks), dim3(256), 0, st, s, n_float4, k); break;
+    switch (aux) { RA(0) RA(1) RA(2) RA(3) RA(16) RA(17) RA(18) RA(19) default: return -1; }
+#undef RA
+    return (int)hipGetLastError();
+}
