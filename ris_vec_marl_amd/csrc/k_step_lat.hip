@@ -341,8 +341,9 @@ bool step_fused_lat_covers(int V, int M) {
     return (V == 4 || V == 8 || V == 16) && (M & 1) == 0 && M >= 2 && M <= 256;
 }
 
-// Shapes whose fused step can read theta as the BCD sweep's candidate indices (RISVEC_STEP_THETA_BY_INDEX)
-bool theta_by_index_supported(int V, int M) { return (V == 8 && M == 64) || (V == 16 && M == 256); }
+// Shapes whose fused step can read theta as the BCD sweep's candidate indices (RISVEC_STEP_THETA_BY_INDEX): every
+// shape this family covers (the EMAX-envs-per-wavefront member of each shape has a TK form)
+bool theta_by_index_supported(int V, int M) { return step_fused_lat_covers(V, M); }
 
 // Single step.  Which kernel, in order:
 //   1. h_r + theta of one step beyond lat_nt_from (1.29 x the Infinity Cache): EMAX envs per wavefront, non-temporal
@@ -392,25 +393,25 @@ hipError_t launch_step_fused_lat(const RisVecState& s, const RisVecParams& p, co
         return launch_single<S8x64, 1, 4, true>(s, p, a, epwt, nt, st);
     }
     if (V == 4 && M == 16) {
-        if (!nt && !band && !below(24)) return hipErrorNotSupported;
-        return launch_single<S4x16, 1, 4, false>(s, p, a, epwt, nt, st);
+        if (!nt && !band && !a.theta_k && !below(24)) return hipErrorNotSupported;
+        return launch_single<S4x16, 1, 4, true>(s, p, a, epwt, nt, st);
     }
     if (V == 16 && M == 64) {
         // (tools/gpu_v16.sh, us per step pipeline / this: 4 096 envs 8.0 / 7.0, 8 192 14.5 / 14.5, from 16 384 the pipeline wins)
-        if (!below(8)) return hipErrorNotSupported;
-        return launch_single<S16x64, 1, 4, false>(s, p, a, epwt, false, st);
+        if (!below(8) && !a.theta_k) return hipErrorNotSupported;
+        return launch_single<S16x64, 1, 4, true>(s, p, a, epwt, false, st);
     }
     if (off && ((V == 8 && (M == 36 || M == 40)) || (V == 16 && M == 256)))
         return hipErrorNotSupported;                           // bit-identity tests: force the pipeline where one exists
-    if (V == 8 && M == 36) return launch_single<S8x36, 1, 4, false>(s, p, a, epwt, nt, st);
-    if (V == 8 && M == 40) return launch_single<S8x40, 1, 4, false>(s, p, a, epwt, nt, st);
+    if (V == 8 && M == 36) return launch_single<S8x36, 1, 4, true>(s, p, a, epwt, nt, st);
+    if (V == 8 && M == 40) return launch_single<S8x40, 1, 4, true>(s, p, a, epwt, nt, st);
     // 16 x 256 (one env = 34 loads per lane): one env per wavefront at every size (tools/gpu_v16.sh: 2 048 envs
     // 14.6 -> 13.5 us, 4 096 25.3 -> 23.4; BASELINE configs[4] with the BCD sweep 251.5 -> 233 us per step)
     if (V == 16 && M == 256) return launch_single<S16x256, 1, 1, true>(s, p, a, 1, nt, st);
     // run-time M: the member with this (V, G, NIT)
     const int g = fused_g(V, M), nit = fused_nit(V, M);
 #define RISVEC_RT(VV, GG, NN, EMIN, EMAX) \
-    if (V == VV && g == GG && nit == NN) return launch_single<FusedShape<VV, GG, NN, 0>, EMIN, EMAX, false>(s, p, a, epwt, nt, st);
+    if (V == VV && g == GG && nit == NN) return launch_single<FusedShape<VV, GG, NN, 0>, EMIN, EMAX, true>(s, p, a, epwt, nt, st);
     RISVEC_RT(8, 8, 1, 2, 4) RISVEC_RT(8, 16, 1, 2, 4) RISVEC_RT(8, 32, 1, 2, 4) RISVEC_RT(8, 64, 1, 2, 4) RISVEC_RT(8, 64, 2, 2, 4)
     RISVEC_RT(4, 16, 1, 2, 4) RISVEC_RT(4, 32, 1, 2, 4) RISVEC_RT(4, 64, 1, 2, 4) RISVEC_RT(4, 64, 2, 2, 4)
     RISVEC_RT(16, 8, 1, 2, 4) RISVEC_RT(16, 16, 1, 2, 4) RISVEC_RT(16, 32, 1, 2, 4) RISVEC_RT(16, 64, 1, 1, 2) RISVEC_RT(16, 64, 2, 1, 1)

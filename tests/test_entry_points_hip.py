@@ -609,7 +609,8 @@ def test_runtime_m_kernel_forms_agree(E, V, M):
 
 
 # ---------------------------------------------------------------------------- theta kept by index (lazy_theta)
-@pytest.mark.parametrize("V,M,E", [(16, 256, 96), (8, 64, 300), (8, 64, 5000)])
+@pytest.mark.parametrize("V,M,E", [(16, 256, 96), (8, 64, 300), (8, 64, 5000), (8, 36, 300), (8, 100, 257), (4, 24, 200),
+                                   (16, 64, 150), (16, 20, 100), (8, 250, 64)])
 def test_theta_by_index_is_bit_identical(V, M, E):
     """`lazy_theta=True`: between BCD sweeps theta lives as one candidate index per element -- `step(bcd=True)` takes the
     sweep that does not write the complex64 tensor (RISVEC_STEP_THETA_BY_INDEX) and the fused step kernel that expands
