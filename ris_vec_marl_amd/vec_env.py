@@ -101,6 +101,7 @@ class VecEnviron(ParamAttrs):
         # materialised when somebody asks for it (`tensors`, any other consumer).  Same step outputs bit for bit.
         self.lazy_theta = bool(lazy_theta)
         self._theta_stale = False      # tensors["theta"] lags behind theta_idx (only ever True with lazy_theta)
+        self._tk_ok = None             # does the fused step have a theta-by-index form at this shape? (asked lazily)
         self._cstate: Optional[N.RisVecState] = None
         self._cparams: Optional[N.RisVecParams] = None
         self._cparams_version = -1
@@ -220,8 +221,11 @@ class VecEnviron(ParamAttrs):
 
     def _by_index(self, fused: bool, steer: bool) -> bool:
         """Can this fused step read theta as candidate indices?  (lazy_theta, indices current, a shape with that form)"""
-        return (self.lazy_theta and fused and not steer and self._idx_valid and self.control_bit == 3
-                and bool(N.load().risvec_theta_by_index_supported(self.n_veh, self.M)))
+        if not (self.lazy_theta and fused and not steer and self._idx_valid and self.control_bit == 3):
+            return False
+        if self._tk_ok is None:                  # asked once: the answer depends on the shape only
+            self._tk_ok = bool(N.load().risvec_theta_by_index_supported(self.n_veh, self.M))
+        return self._tk_ok
 
     def __getattr__(self, name):
         t = self.__dict__.get("_t")
