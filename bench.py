@@ -517,6 +517,8 @@ def run_leg(name, E, V, M, mode, device, rank, world, steps, warmup, gather_ever
            "roofline_frac": per_env * E / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "roofline_frac_wall": per_env * E / (dt / steps) / 1e9 / HBM_PEAK_GBS,
            "kernel": case.kernel_name(), "allgather": case.gather_note}
+    if getattr(case.env, "placement", None):
+        out["stream_placement"] = case.env.placement
     if mode == "bcd":
         out["bcd_candidate_evals_per_s"] = E * world * steps / dt * M * 8
         out["theta"] = ("kept as the sweep's candidate indices between sweeps (VecEnviron.lazy_theta): the sweep does not write "
@@ -709,6 +711,7 @@ def main() -> None:
     dt, kernel_ms = case.run(args.steps, args.warmup, world)
     gather_ok = getattr(case, "gather_ok", True)
     case_ring_fused = getattr(case, "ring_fused", False)
+    case_placement = getattr(getattr(case, "env", None), "placement", None)    # h_r placed by measurement (streams beyond the cache)
     fused, bcd, full = case.fused, case.bcd, case.full
     per_env = case.per_env_bytes()
     gather_note = case.gather_note
@@ -793,6 +796,7 @@ def main() -> None:
     if bcd:
         out["config"]["bcd_candidate_evals_per_s"] = E * world * args.steps / dt * M * 8
     out["config"]["allgather_backend"] = torch.distributed.get_backend() if world > 1 else "none"
+    out["config"]["stream_placement"] = case_placement
     out["cpu_baseline"] = cpu
     if STUB:      # a self-test line can never be mistaken for a measurement
         out.update(metric="launcher self-test (no GPU work)", value=None, stub=True, data="stub", max_over_ranks_s=dt,

@@ -164,6 +164,60 @@ class VecEnviron(ParamAttrs):
             setattr(s, k, t[k].data_ptr())
         s.h_d = None
         self._cstate = s
+        self._place_stream()
+
+    # how the h_r allocation was chosen (None: not needed / switched off); bench.py reports it
+    placement: Optional[dict] = None
+
+    def _place_stream(self) -> None:
+        """h_r is THE stream of the fused step.  Once it no longer fits the Infinity Cache, the rate at which the kernels
+        stream it depends on WHERE the allocation landed in HBM: two levels ~8 % apart, a property of the allocation (in
+        one process the first few GB handed out stream slower than later ones; `tools/placement_probe.py`,
+        EXPERIMENTS.md round 3).  So the stream is placed by measurement: up to 10 candidate allocations are timed with
+        the fused step kernel itself (on the all-zero state, wiped afterwards) and the fastest is kept; the
+        others go back to torch's allocator.  A few milliseconds at construction, at most 25 % of the free memory in
+        flight; RISVEC_NO_PLACEMENT=1 switches it off."""
+        import os
+        t = self._t
+        nbytes = t["h_r"].numel() * 4
+        if nbytes <= (256 << 20) or os.environ.get("RISVEC_NO_PLACEMENT"):
+            return
+        free, _ = torch.cuda.mem_get_info(self.device)
+        n_max = min(10, 1 + int(0.25 * free // nbytes))
+        if n_max < 2:
+            return
+        lib, cs, pp, stream = N.load(), C.byref(self._cstate), C.byref(self._p()), self._stream()
+        E, V = self.n_envs, self.n_veh
+        act = torch.zeros(E, 2, V, device=self.device)
+        part = torch.full((E, V), -1, dtype=torch.int32, device=self.device)
+        ngr = torch.full((E,), V, dtype=torch.int32, device=self.device)
+        flags = N.STEP_METRICS | N.STEP_OBS
+
+        def gain_us(h) -> float:                       # the fused step itself on an all-zero state (wiped afterwards)
+            self._cstate.h_r = h.data_ptr()
+            best = float("inf")
+            for i in range(4):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                N.check(lib.risvec_step_fused(cs, pp, act.data_ptr(), part.data_ptr(), ngr.data_ptr(), None, self.seed, i, flags,
+                                              stream))
+                b.record()
+                b.synchronize()
+                if i:                                  # the first launch warms the code path
+                    best = min(best, a.elapsed_time(b) * 1e3)
+            return best
+
+        cands = [(gain_us(t["h_r"]), t["h_r"])]
+        while len(cands) < n_max:
+            c = torch.zeros_like(cands[0][1])
+            cands.append((gain_us(c), c))
+            if min(x[0] for x in cands) < 0.96 * max(x[0] for x in cands):
+                break                                  # both levels seen: the faster one is known
+        us, keep = min(cands, key=lambda x: x[0])
+        t["h_r"] = keep
+        self._cstate.h_r = keep.data_ptr()
+        self.placement = dict(candidates=len(cands), step_kernel_us=[round(x[0], 1) for x in cands], kept_us=round(us, 1))
+        self._out_slab.zero_()                         # the timing steps ran on (and dirtied) the all-zero state
 
     def set_direct_link(self, h_d: Optional[torch.Tensor]) -> None:
         """Optional direct BS link amplitude h_d [E,V] complex64 (the reference has none:

@@ -21,9 +21,10 @@ def finite(env, keys=("gain", "reward", "data_buf", "mec_q", "rate", "obs", "met
     assert (env.tensors["reward"].abs() <= clip * (1 + 1e-6)).all()
 
 
-def phase(name, E, V, M, n, **kw):
+def phase(name, E, V, M, n, lazy=False, **kw):
     rng = np.random.default_rng(1)
     env = build_env(E, V, M, dev, 3, 0)
+    env.lazy_theta = lazy
     action = torch.from_numpy(rng.uniform(0, 1, (E, 2, V)).astype(np.float32)).to(dev)
     p, g = synthetic_groups(E, V, rng)
     partner, ng = torch.from_numpy(p).to(dev), torch.from_numpy(g).to(dev)
@@ -70,7 +71,13 @@ phase("headline fused 32768x8x64", 32768, 8, 64, n(4000))
 phase("configs[1] fused 4096x8x36", 4096, 8, 36, n(8000))
 phase("configs[3] shard fused 8192x8x64", 8192, 8, 64, n(8000))
 phase("configs[4] bcd 32768x16x256", 32768, 16, 256, n(600), bcd=True)
+phase("configs[4] bcd, theta by index", 32768, 16, 256, n(600), lazy=True, bcd=True)
+phase("bcd, theta by index, run-time M 8192x8x100", 8192, 8, 100, n(1500), lazy=True, bcd=True)
 phase("beyond the cache 262144x8x64", 262144, 8, 64, n(300))
+phase("just beyond the cache (alternating walk) 65536x8x64", 65536, 8, 64, n(1500))
+phase("run-time M 32768x8x120", 32768, 8, 120, n(2000))
+phase("run-time M 20000x16x50", 20000, 16, 50, n(2000))
+phase("run-time M 50000x4x24", 50000, 4, 24, n(4000))
 phase("cached step 32768x8", 32768, 8, 64, n(8000), fused=False)
 phase("reference default 16384x8x40", 16384, 8, 40, n(4000))
 tstep_phase("T-step fused 4096x8x36", 4096, 8, 36, 32, n(60), True)
