@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RISVEC_ABI_VERSION 14
+#define RISVEC_ABI_VERSION 15
 #define RISVEC_POISSON_TABLE 64   /* entries of the arrival CDF table            */
 #define RISVEC_MAX_LANES 8        /* lane coordinates per direction (ref. has 4) */
 #define RISVEC_MAX_VEH 64         /* V <= 64: one env's vehicles fit a wavefront */
@@ -410,7 +410,15 @@ typedef struct RisVecNomaState {
     uint8_t *mask;                  /* [E,N,N] last_mask_mat (0/1)                          */
     double *tau;                    /* [E]     last_tau_now                                 */
     int32_t *pending;               /* [E]     frozen steps not yet applied to hist / streak */
+    void *scratch;                  /* risvec_noma_scratch_bytes(E, N) bytes of ZEROED device memory (NULL when that is 0):
+                                       beyond 8 vehicles risvec_noma_group is two launches, and this is the list of envs
+                                       the first leaves to the second (a pairing graph too dense for its on-chip table) */
+    int64_t scratch_bytes;
 } RisVecNomaState;
+
+/* Scratch risvec_noma_group needs for this batch: 0 up to 8 vehicles, 16 B + 4 B per env (rounded up to 256 B) beyond.
+ * Zero it once when it is allocated; every call leaves it zeroed. */
+int64_t risvec_noma_scratch_bytes(int32_t n_envs, int32_t n_veh);
 
 void risvec_noma_default_params(RisVecNomaParams *p, int32_t n_veh);   /* driver Config defaults */
 

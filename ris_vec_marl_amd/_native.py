@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 POISSON_TABLE = 64
 MAX_LANES = 8
 MAX_VEH = 64
@@ -108,6 +108,7 @@ class RisVecNomaState(C.Structure):
         ("n_envs", C.c_int32), ("n_veh", C.c_int32), ("env_offset", C.c_int64),
         ("hist", _FP), ("streak", _FP), ("partner", _FP), ("n_groups", _FP), ("last_global", _FP),
         ("best_global", _FP), ("flags", _FP), ("mask", _FP), ("tau", _FP), ("pending", _FP),
+        ("scratch", _FP), ("scratch_bytes", C.c_int64),
     ]
 
 
@@ -175,6 +176,7 @@ _PROTOS = {
                                         C.c_int32, C.c_int32, _FP, _FP, C.c_int32, C.c_int32, _FP,
                                         C.c_uint64, C.c_uint32, _FP, _FP]),
     "risvec_noma_flush": (C.c_int, [C.POINTER(RisVecNomaState), C.POINTER(RisVecNomaParams), _FP]),
+    "risvec_noma_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "risvec_replay_store": (C.c_int, [C.POINTER(RisVecReplay), C.c_int64, C.c_int32, _FP, _FP, _FP, C.c_int32, _FP,
                                       _FP, _FP, C.c_int32, _FP, _FP, _FP]),
     "risvec_replay_store_policy": (C.c_int, [C.POINTER(RisVecReplay), C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, C.c_int32, _FP,

@@ -17,18 +17,28 @@
 // the lanes; every decision the reference takes by comparing float64 numbers is taken by comparing
 // float64 numbers formed in the same association order (fp contraction is off for the whole file:
 // the matcher's exact ties are decided by last-bit rounding, see EXPERIMENTS.md, section 8 f2).
-//   * quantiles: no sort -- each lane ranks its own entries against all (LDS broadcast reads) and
-//     the two order statistics NumPy's linear method interpolates are picked by rank;
+//   * quantiles: up to 8 users (64 entries, one per lane) each lane ranks its entry against all (LDS
+//     broadcast reads); beyond that (256 entries, four per lane) the wavefront sorts them with a
+//     bitonic network in registers (n^2 float64 compares were a third of a solve); either way the two
+//     order statistics NumPy's linear method interpolates are picked by rank;
 //   * matching: the reference's memoised recursion on the lowest unused user x, evaluated bottom-up
 //     in layers of x (a state only needs states with a larger x), after dropping users without any
 //     admissible edge (they pass the value through unchanged).  Only states the recursion can reach
-//     are stored: with x the lowest unused user at most x users above it are taken, which leaves
-//     2 583 of the 65 536 masks at 16 users; they are indexed by (x, size, colex rank) so the table
-//     fits LDS for every K <= 16;
+//     are stored.  Up to 8 users the table is simply indexed by the mask.  Beyond that it is indexed
+//     by the FRONTIER: the users above x that can already be taken when x is the lowest unused one are
+//     partners of somebody below x, F(x) = {j > x : (x', j) admissible for an x' < x}, so layer x holds
+//     at most 2^|F(x)| states -- a few dozen in all for the sparse graphs the accept quantile leaves,
+//     instead of 2^K; on the complete graph it is every mask the recursion could reach on any graph
+//     (at most x users taken above x: 2 583 of the 65 536 masks at 16 users).  An env whose table
+//     exceeds 256 states (about 1 % of them) is left to a second launch that has the LDS for it;
 //   * completion: repeated wave-wide arg-max over the still-free admissible edges, which is what
 //     the reference's sorted greedy scan selects.
-// This is integer / branchy float64 work of a few hundred bytes per env; it is latency-bound.
+// This is integer / branchy float64 work of a few hundred bytes per env; it is latency-bound, which
+// is why the 16-user kernel's LDS is kept to 9 KB: four wavefronts per SIMD instead of one.
 #include "risvec_launch.hpp"
+
+#include <cstdlib>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -57,6 +67,9 @@ struct NomaArgs {
     uint64_t seed;
     uint32_t counter;
     int32_t* info_out;
+    void* scratch;               // Deferred (more than 8 users): the envs the first launch leaves to the second
+    long long* stamps;           // diagnostic build only
+    double qos_y_lo, qos_y_hi;   // 2^qos_R_min -/+ 1e-9 relative: outside this band log2(y) >= R_min is decided without the log2
 };
 
 __device__ __forceinline__ double wave_max(double x) {
@@ -167,13 +180,26 @@ k_noma_clear_pending(RisVecNomaState ns) {
 // ---------------------------------------------------------------------------------------------
 // group: a wavefront per 8 envs -- bookkeeping by 8 lanes, then one full-wave solve per env that needs it
 // ---------------------------------------------------------------------------------------------
-template <int NMAX>
+constexpr int kReachMax = 2583;                        // masks the recursion can reach at 16 users (at most x users taken above x)
+constexpr int kTabMax = 2640;                          // >= the largest frontier table: kReachMax, + 49 when layer 1 stores 64
+                                                       // states `direct` where the complete graph has 15 (see Layer)
+// MODE 0: the kernel every group() call launches.  MODE 1 (more than 8 users only): the second launch, one wavefront per
+// env whose matching table did not fit MODE 0's -- about 1 % of the envs (all gains at the floor: every score equal,
+// every edge admitted) -- with LDS for the largest table there is.  Keeping that table out of MODE 0 is what lets it
+// run four wavefronts per SIMD instead of one.
+template <int NMAX, int MODE = 0>
 struct Shape {
     static constexpr int NN = NMAX * NMAX;
     static constexpr int EPL = NN / kWave;             // matrix entries per lane
-    static constexpr int DP = NMAX <= 8 ? 256 : 2600;  // matching table: 2^8 masks / the 2 583 reachable states at 16
-    static constexpr int KPLAIN = NMAX <= 8 ? 8 : 11;  // up to here the table is simply indexed by the mask
+    static constexpr bool BIG = NMAX > 8;              // more than 8 users: sorted quantiles, frontier-indexed matching table
+    static constexpr int DP = !BIG ? 256 : (MODE == 0 ? 256 : kTabMax);   // LDS table entries (up to 8 users: the 2^8 masks)
 };
+// Scratch of the two-launch scheme: the envs MODE 0 left for MODE 1.
+struct Deferred {
+    int count, done, pad[2];
+    int env[1];                                        // [n_envs]
+};
+constexpr int kDeferredGridMax = 512;
 
 template <int EPL>
 struct Ranks {
@@ -214,10 +240,89 @@ __device__ __forceinline__ double order_stat(const Ranks<EPL>& R, int k) {   // 
     return wave_max(v);
 }
 
+// 256 values, four per lane, sorted ascending across the wavefront: position p is v[p & 3] of lane p >> 2.
+// Bitonic network on element index e = 4 lane + t: the exchanges at distance 1 and 2 stay inside a lane, the
+// others pair lane with lane ^ (distance / 4).  Ranking 256 entries against each other took 2 x 256 float64
+// compares per entry (a third of a 16-user solve); this is 36 stages of one compare per entry.
+struct Sorted4 {
+    double v[4];
+    int cnt;
+};
+__device__ __forceinline__ void cmpx(double& a, double& b, bool asc) {
+    const bool sw = asc ? b < a : a < b;
+    const double lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
+template <int D>
+__device__ __forceinline__ void cmpx_lanes(double (&v)[4], int lane, bool asc) {
+    const bool keep_min = ((lane & D) == 0) == asc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double other = __shfl_xor(v[t], D, kWave);
+        const bool take = keep_min ? other < v[t] : v[t] < other;
+        v[t] = take ? other : v[t];
+    }
+}
+__device__ __forceinline__ void cmpx_in_lane(double (&v)[4], bool asc) {
+    cmpx(v[0], v[2], asc);
+    cmpx(v[1], v[3], asc);
+    cmpx(v[0], v[1], asc);
+    cmpx(v[2], v[3], asc);
+}
+__device__ __forceinline__ void sort256(double (&v)[4], int lane) {
+    cmpx(v[0], v[1], true);                            // runs of 2: up, down
+    cmpx(v[2], v[3], false);
+    cmpx_in_lane(v, (lane & 1) == 0);                  // runs of 4
+    bool asc = (lane & 2) == 0;                        // runs of 8
+    cmpx_lanes<1>(v, lane, asc);
+    cmpx_in_lane(v, asc);
+    asc = (lane & 4) == 0;                             // 16
+    cmpx_lanes<2>(v, lane, asc);
+    cmpx_lanes<1>(v, lane, asc);
+    cmpx_in_lane(v, asc);
+    asc = (lane & 8) == 0;                             // 32
+    cmpx_lanes<4>(v, lane, asc);
+    cmpx_lanes<2>(v, lane, asc);
+    cmpx_lanes<1>(v, lane, asc);
+    cmpx_in_lane(v, asc);
+    asc = (lane & 16) == 0;                            // 64
+    cmpx_lanes<8>(v, lane, asc);
+    cmpx_lanes<4>(v, lane, asc);
+    cmpx_lanes<2>(v, lane, asc);
+    cmpx_lanes<1>(v, lane, asc);
+    cmpx_in_lane(v, asc);
+    asc = (lane & 32) == 0;                            // 128
+    cmpx_lanes<16>(v, lane, asc);
+    cmpx_lanes<8>(v, lane, asc);
+    cmpx_lanes<4>(v, lane, asc);
+    cmpx_lanes<2>(v, lane, asc);
+    cmpx_lanes<1>(v, lane, asc);
+    cmpx_in_lane(v, asc);
+    cmpx_lanes<32>(v, lane, true);                     // 256
+    cmpx_lanes<16>(v, lane, true);
+    cmpx_lanes<8>(v, lane, true);
+    cmpx_lanes<4>(v, lane, true);
+    cmpx_lanes<2>(v, lane, true);
+    cmpx_lanes<1>(v, lane, true);
+    cmpx_in_lane(v, true);
+}
+__device__ __forceinline__ double order_stat(const Sorted4& R, int k) {       // k wave-uniform
+    // (the four values pass through opaque moves: a select between loads of R.v[] is otherwise folded into ONE load at a
+    // selected address, and an array indexed at run time lives in scratch memory)
+    double a = R.v[0], b = R.v[1], c = R.v[2], d = R.v[3];
+    asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    double sel = a;
+    if ((k & 3) == 1) sel = b;
+    if ((k & 3) == 2) sel = c;
+    if ((k & 3) == 3) sel = d;
+    return __shfl(sel, k >> 2, kWave);
+}
+
 // np.quantile(values, q), method 'linear': virtual index (n-1) q, neighbours floor / floor+1 (both
 // the last element from n-1 up), two-sided lerp (a + d t below t = 0.5, b - d (1-t) from there).
-template <int EPL>
-__device__ __forceinline__ double quantile_linear(const Ranks<EPL>& R, double q) {
+template <class RK>
+__device__ __forceinline__ double quantile_linear(const RK& R, double q) {
     const int n = R.cnt;
     const double vi = (double)(n - 1) * q;
     int lo = (int)floor(vi), hi;
@@ -232,73 +337,287 @@ __device__ __forceinline__ double quantile_linear(const Ranks<EPL>& R, double q)
     return r;
 }
 
-// Matching table: value of the recurrence at a reachable mask.  x = lowest unused user, T = users
-// taken above x (|T| <= x); slot = base[x] + (number of smaller subsets of the K-1-x upper users)
-// + colex rank of T among the subsets of its size.
-struct MatchTab {
-    const double* dp;
-    const int* base;       // [K+1]
-    const int* sizeoff;    // [16][kBinW + 1]
-    const uint16_t* clo;   // [256]      colex rank of the low 8 bits of T
-    const uint16_t* chi;   // [9][128]   colex rank contribution of bits 8.. of T, given popcount(low 8)
-    int K, full;
-    bool plain;            // 2^K fits the table: slot = mask (no ranking arithmetic on the critical path)
-    __device__ __forceinline__ int slot(int mask) const {
-        if (plain) return mask;
-        const int x = __ffs(~mask) - 1;
-        unsigned T = (unsigned)mask >> (x + 1);
+// ---- matching tables: value / choice of the recurrence at a mask, three ways of finding its slot -------------------
+// (compressed users 0..K-1; x = lowest unused user of the mask, T = the users taken above x)
+struct PlainTab {                                      // slot = mask
+    double* dp;
+    signed char* arg;
+    int full;
+    __device__ __forceinline__ int slot(int mask) const { return mask; }
+    __device__ __forceinline__ double value(int mask) const { return mask == full ? 0.0 : dp[mask]; }
+};
+
+// Binomial sums for ranking subsets by (size, colex order): compile-time tables in constant memory, read only for the
+// (rare) layers too wide to store every subset of their frontier.
+struct ColexTab {
+    int sizeoff[16 * (kBinW + 1)];                     // [c][i] = sum_{i' < i} C(c, i')
+    uint16_t clo[256];                                 // colex rank of the low 8 bits of a subset
+    uint16_t chi[9 * 128];                             // contribution of bits 8.., given popcount(low 8)
+};
+constexpr ColexTab make_colex() {
+    ColexTab t{};
+    int binom[16][kBinW] = {};                         // C(c, i), i < kBinW (larger i never ranks: at most 8 of <= 15 taken)
+    for (int c = 0; c < 16; ++c)
+        for (int i = 0; i < kBinW; ++i) binom[c][i] = i == 0 ? 1 : (c == 0 ? 0 : binom[c - 1][i - 1] + binom[c - 1][i]);
+    for (int c = 0; c < 16; ++c) {
+        int off = 0;
+        for (int i = 0; i <= kBinW; ++i) {
+            t.sizeoff[c * (kBinW + 1) + i] = off;
+            if (i < kBinW) off += binom[c][i];
+        }
+    }
+    for (int b = 0; b < 256; ++b) {                    // sum over set bits c_1 < c_2 < ... of C(c_i, i)
+        int r = 0, i = 1;
+        for (int c = 0; c < 8; ++c)
+            if ((b >> c) & 1) { r += i < kBinW ? binom[c][i] : 0; ++i; }
+        t.clo[b] = (uint16_t)r;
+    }
+    for (int e = 0; e < 9 * 128; ++e) {                // bits 8.. (positions 8 + c), ranks continue at p + 1
+        int r = 0, i = e / 128 + 1;
+        for (int c = 0; c < 7; ++c)
+            if (((e % 128) >> c) & 1) { r += i < kBinW ? binom[8 + c][i] : 0; ++i; }
+        t.chi[e] = (uint16_t)r;
+    }
+    return t;
+}
+__constant__ const ColexTab kColex = make_colex();
+constexpr int reachable_masks(int K) {                 // table size of the complete graph on K users
+    const ColexTab t = make_colex();
+    int off = 0;
+    for (int x = 0; x < K; ++x) {
         const int n = K - 1 - x;
-        const unsigned lo = T & 255u, hi = T >> 8;
-        return base[x] + sizeoff[n * (kBinW + 1) + __popc(T)] + clo[lo] + chi[__popc(lo) * 128 + hi];
+        off += t.sizeoff[n * (kBinW + 1) + (x < n ? x : n) + 1];
+    }
+    return off;
+}
+static_assert(reachable_masks(16) == kReachMax && kTabMax >= kReachMax - 15 + 64, "kTabMax holds the largest table there is");
+
+// Frontier-indexed table.  With x the lowest unused user, every user taken above x is the partner of somebody below x:
+// T is a subset of F(x) = {j > x : (x', j) admissible for an x' < x}, of at most cap(x) = #{x' < x with an edge to above x}
+// users.  Layer x stores those subsets: all 2^|F(x)| of them when that is at most a wavefront's worth (`direct`, slot =
+// base[x] + T's bits gathered at the positions of F(x)), otherwise only the ones of size <= cap(x), ranked by (size, colex
+// order).  On the sparse graphs the accept quantile leaves this is a few dozen states; on the complete graph it is the
+// table of every mask the recursion can reach on any graph (2 583 states at 16 users).  No table is larger than that one
+// by more than 49 states: a ranked layer holds at most what the complete graph's does (cap(x) <= x, |F(x)| <= 15 - x), and
+// so does a direct one (<= 64 states) except layer 1, where the complete graph has 15.
+struct Layer {
+    unsigned long long pos;                            // 4 bits per user j: the rank of j in F(x)
+    int base;                                          // first slot of the layer
+    unsigned meta;                                     // F(x) | |F(x)| << 16 | cap(x) << 20 | direct << 24
+};
+__device__ __forceinline__ int rank_in_layer(const ColexTab* cx, unsigned meta, unsigned c) {   // c = T gathered at F(x)'s positions
+    if (meta >> 24) return (int)c;
+    const unsigned nf = (meta >> 16) & 15u, lo = c & 255u, hi = c >> 8;
+    return cx->sizeoff[nf * (kBinW + 1) + __popc(c)] + cx->clo[lo] + cx->chi[__popc(lo) * 128 + hi];
+}
+struct FrontTab {
+    double* dp;                                        // LDS, or the caller's scratch when the table is larger than Shape::DP
+    signed char* arg;
+    const Layer* layer;                                // [K]
+    const ColexTab* colex;                             // constant memory, or the second launch's copy in LDS
+    int full, last;                                    // last = table size - 1
+    __device__ __forceinline__ int slot(int mask) const {
+        const int x = __ffs(~mask) - 1;
+        const Layer L = layer[x];
+        unsigned c = 0;
+        for (unsigned m = (unsigned)mask & ~((2u << x) - 1u); m; m &= m - 1) c |= 1u << ((L.pos >> (4 * (__ffs(m) - 1))) & 15u);
+        // (states that are stored but cannot be reached may ask for one that is not stored: whatever they read is never
+        // used, but it has to be read inside the table)
+        return min(L.base + rank_in_layer(colex, L.meta, c), last);
     }
     __device__ __forceinline__ double value(int mask) const { return mask == full ? 0.0 : dp[slot(mask)]; }
 };
+
+// solve_at for the frontier table, FOUR options at a time: their layer records are read together, then their table
+// values, then they are folded in the reference's order (single first, partners by increasing j).  One option after the
+// other is two dependent LDS round trips each; a state of the complete graph has a dozen.
+__device__ __forceinline__ void solve_at_front(const FrontTab& M, const double* w, unsigned adj_x, bool singles, int x, int mask,
+                                               int sl) {
+    const int m1 = mask | (1 << x);
+    double best = -kInf;
+    int arg = -2;
+    unsigned cand = adj_x & ~(unsigned)mask;
+    bool single_pending = singles;
+    do {
+        int jj[4], xs[4];
+        unsigned tt[4], cc[4];
+        bool ok[4], is_full[4];
+        Layer L[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool take = !(k == 0 && single_pending) && cand != 0;
+            ok[k] = take || (k == 0 && single_pending);
+            jj[k] = take ? __ffs(cand) - 1 : -1;
+            if (take) cand &= cand - 1;
+            int m = jj[k] >= 0 ? m1 | (1 << jj[k]) : m1;
+            is_full[k] = m == M.full;
+            if (is_full[k]) m = mask;                  // any stored state: its value is not used
+            xs[k] = __ffs(~m) - 1;
+            tt[k] = (unsigned)m & ~((2u << xs[k]) - 1u);
+        }
+        single_pending = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) L[k] = M.layer[xs[k]];
+        unsigned rest = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned c = 0, m = tt[k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {              // three taken users without a branch, the (rare) rest in a loop
+                const int b = m ? __ffs(m) - 1 : 0;
+                c |= m ? 1u << ((L[k].pos >> (4 * b)) & 15u) : 0u;
+                m &= m - 1;
+            }
+            cc[k] = c;
+            tt[k] = m;
+            rest |= m;
+        }
+        if (rest) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                for (unsigned m = tt[k]; m; m &= m - 1) cc[k] |= 1u << ((L[k].pos >> (4 * (__ffs(m) - 1))) & 15u);
+        }
+        double v[4], we[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = min(L[k].base + rank_in_layer(M.colex, L[k].meta, cc[k]), M.last);
+            v[k] = M.dp[s];
+            we[k] = w[x * kNV + max(jj[k], 0)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double vk = is_full[k] ? 0.0 : v[k];
+            if (!ok[k]) continue;
+            if (jj[k] < 0) {
+                if (vk > best) { best = vk; arg = -1; }
+            } else if (finite(vk) && we[k] + vk > best) {
+                best = we[k] + vk;
+                arg = jj[k];
+            }
+        }
+    } while (cand);
+    M.dp[sl] = arg == -2 ? 0.0 : best;                 // TRAIN:389-390
+    M.arg[sl] = (signed char)arg;
+}
 
 // Value and choice of the recurrence at `mask` (TRAIN:360-391): the lowest unused user x stays single
 // (arg -1) or takes partner j (arg j); arg -2 = no option (value 0, nothing below it).
 // `adj[x]`: bit j set when (x, j), j > x, is an admissible edge -- the partners are walked in increasing j
 // by peeling set bits, so a sparse graph (the usual case: only the top-quantile edges survive) costs a
 // couple of iterations per state instead of one per user.
-__device__ __forceinline__ double best_at(const MatchTab& M, const double* w, const int* adj, bool singles, int mask,
-                                          int& arg) {
-    const int x = __ffs(~mask) - 1;
+template <class Tab>
+__device__ __forceinline__ void solve_at(const Tab& M, const double* w, unsigned adj_x, bool singles, int x, int mask, int sl) {
     double best = -kInf;
-    arg = -2;
+    int arg = -2;
     if (singles) {
         const double w1 = M.value(mask | (1 << x));
         if (w1 > best) { best = w1; arg = -1; }
     }
-    for (unsigned cand = (unsigned)adj[x] & ~(unsigned)mask; cand; cand &= cand - 1) {
+    for (unsigned cand = adj_x & ~(unsigned)mask; cand; cand &= cand - 1) {
         const int j = __ffs(cand) - 1;
         const double we = w[x * kNV + j];
         const double w2 = M.value(mask | (1 << x) | (1 << j));
         if (finite(w2) && we + w2 > best) { best = we + w2; arg = j; }
     }
-    return best;
+    M.dp[sl] = arg == -2 ? 0.0 : best;                 // TRAIN:389-390
+    M.arg[sl] = (signed char)arg;
 }
 
-// Envs per wavefront: as many wavefronts as the chip keeps resident when every env solves (8 users: ~20
-// wavefronts per CU fit -> 8 envs each at 32 768 envs; 16 users: the 32 KB of LDS allow ~4 per CU -> 32
-// envs each), so a frozen step launches no more blocks than that.
-template <int NMAX> struct EnvsPerWave { static constexpr int value = NMAX <= 8 ? 8 : 32; };
+// Layers of x from the top, table indexed by the mask: every mask with at most x users taken above x (up to 8 users).
+__device__ __forceinline__ void solve_plain(const PlainTab& M, const double* w, const int* adj, bool singles, int K, int lane) {
+    for (int x = K - 1; x >= 0; --x) {                 // a state only needs states with a larger x
+        const int n = K - 1 - x, low = (1 << x) - 1;
+        for (int T = lane; T < (1 << n); T += kWave) {
+            if (__popc(T) > x) continue;               // not reachable
+            const int m = low | (T << (x + 1));
+            solve_at(M, w, (unsigned)adj[x], singles, x, m, m);
+        }
+        __syncthreads();
+    }
+}
+
+// ... table indexed by the frontier.  `meta` / `base` / `adj`: lane x holds layer x's.  BATCH: four options at a time (the
+// second launch: lone wavefronts on wide tables, all latency; in the first it only costs registers).
+template <bool BATCH>
+__device__ __forceinline__ void solve_frontier(const FrontTab& M, const double* w, unsigned meta, int base, unsigned adj,
+                                               bool singles, int K, int lane) {
+    for (int x = K - 1; x >= 0; --x) {
+        const unsigned mx = (unsigned)__builtin_amdgcn_readlane((int)meta, x);
+        const int bx = __builtin_amdgcn_readlane(base, x);
+        const unsigned adj_x = (unsigned)__builtin_amdgcn_readlane((int)adj, x);
+        const unsigned Fx = mx & 0xFFFFu;
+        const int n_sub = 1 << ((mx >> 16) & 15u), cap = (int)((mx >> 20) & 15u), low = (1 << x) - 1;
+        for (int c = lane; c < n_sub; c += kWave) {
+            if (__popc(c) > cap) continue;             // more taken than users below x could have taken
+            unsigned T = 0;
+            int b = 0;
+            for (unsigned m = Fx; m; m &= m - 1, ++b) T |= (((unsigned)c >> b) & 1u) << (__ffs(m) - 1);
+            const int sl = bx + rank_in_layer(M.colex, mx, (unsigned)c);
+            if constexpr (BATCH) solve_at_front(M, w, adj_x, singles, x, low | (int)T, sl);
+            else solve_at(M, w, adj_x, singles, x, low | (int)T, sl);
+        }
+        __syncthreads();
+    }
+}
+
+// Walk the choices from the empty mask (every lane, same reads) -> pairs in original user numbers.
+template <class Tab>
+__device__ __forceinline__ void walk_choices(const Tab& M, unsigned live, unsigned& busy, unsigned long long& mate,
+                                             int& npairs) {
+    unsigned long long user_of = 0;                    // 4 bits per compressed index: the user it stands for
+    {
+        int c = 0;
+        for (unsigned lm = live; lm; lm &= lm - 1, ++c) user_of |= (unsigned long long)(__ffs(lm) - 1) << (4 * c);
+    }
+    int m = 0;
+    while (m != M.full) {
+        const int arg = M.arg[M.slot(m)];
+        if (arg == -2) break;
+        const int x = __ffs(~m) - 1;
+        m |= 1 << x;
+        if (arg >= 0) {
+            m |= 1 << arg;
+            const int vx = (int)((user_of >> (4 * x)) & 15u), vj = (int)((user_of >> (4 * arg)) & 15u);
+            busy |= (1u << vx) | (1u << vj);
+            mate |= ((unsigned long long)vj << (4 * vx)) | ((unsigned long long)vx << (4 * vj));
+            ++npairs;
+        }
+    }
+}
+
+// Envs per wavefront: as many wavefronts as the chip keeps resident when every env solves (16 to 20 wavefronts
+// per CU fit -> 8 envs each at 32 768 envs), so a frozen step launches no more blocks than that.
+template <int NMAX> struct EnvsPerWave { static constexpr int value = 8; };
 
 // (One long function on purpose: split into inlined helpers over a shared-memory struct the same code ran the
 // 16-user kernel's frozen path 4x slower and its solves 5 % slower, A/B on one box -- the compiler's schedule
 // of this kernel is that sensitive to its shape.)
-template <int NMAX>
-__global__ void __launch_bounds__(kWave, NMAX <= 8 ? 5 : 1)
+// STAMP (diagnostic library only, tools/noma_stamps.py): s_memtime ticks per phase of the solves, summed per block into
+// A.stamps.
+constexpr int kStamps = 12;
+#ifndef RISVEC_NOMA_OCC
+#define RISVEC_NOMA_OCC 4                              // wavefronts per SIMD the 16-user first launch is compiled for
+#endif
+template <int NMAX, int MODE = 0, bool STAMP = false>
+__global__ void __launch_bounds__(kWave, NMAX <= 8 ? 5 : (MODE == 0 ? RISVEC_NOMA_OCC : 1))
 k_noma_group(NomaArgs A) {
     constexpr int kEnvsPerWave = EnvsPerWave<NMAX>::value;
-    using S = Shape<NMAX>;
+    using S = Shape<NMAX, MODE>;
     constexpr int EPL = S::EPL;
-    __shared__ double s_S[S::NN], s_R[S::NN], s_W[S::NN], s_w[kNV * kNV], s_g[kNV], s_lin[kNV], s_p[kNV];
+    constexpr bool BIG = S::BIG;
+    __shared__ double s_S[S::NN], s_w[kNV * kNV], s_g[kNV], s_lin[kNV], s_p[kNV];
+    __shared__ double s_R[BIG ? 1 : S::NN], s_W[BIG ? 1 : S::NN];   // (beyond 8 users: ranks by sorting, W read through s_S)
     __shared__ double s_dp[S::DP];
     __shared__ float s_hist[S::NN];
     __shared__ uint8_t s_feas[S::NN], s_qos[S::NN];
-    __shared__ int s_part[kNV], s_base[kNV + 1], s_adj[kNV], s_binom[16 * kBinW], s_sizeoff[16 * (kBinW + 1)];
+    __shared__ int s_part[kNV], s_adj[kNV];
+    __shared__ unsigned s_live[1];
+    __shared__ Layer s_layer[BIG ? kNV : 1];
+    using ColexLds = std::conditional_t<MODE == 1, ColexTab, int>;       // MODE 1 (its tables are the wide ones) keeps a copy in LDS
+    __shared__ ColexLds s_colex;
+    const ColexTab* colex = &kColex;
+    if constexpr (MODE == 1) colex = &s_colex;
     __shared__ signed char s_arg[S::DP];               // choice taken at each state, for the walk-back
-    constexpr bool kRanked = NMAX > S::KPLAIN;         // more users than the plain 2^K table can hold?
-    __shared__ uint16_t s_clo[kRanked ? 256 : 1], s_chi[kRanked ? 9 * 128 : 1];   // colex-rank lookup
     // a frozen step is a handful of loads and stores per env: every argument it touches in ONE scalar round trip
     RISVEC_ARGS_IN_ONE_TRIP("s"(A.ns.n_envs), "s"(A.ns.n_veh), "s"(A.ns.flags), "s"(A.ns.last_global), "s"(A.ns.best_global),
                             "s"(A.prev_global), "s"(A.prev_stride), "s"(A.ns.pending), "s"(A.ns.n_groups), "s"(A.u_unstick),
@@ -311,73 +630,19 @@ k_noma_group(NomaArgs A) {
 
     int ei[EPL], ej[EPL];                              // this lane's matrix entries
     bool ein[EPL];
-    bool tables_ready = false;
-    // The common case -- a wavefront whose (only) env group is frozen -- is decided and LEAVES here, in front of the loop.
-    // Whatever the solve path keeps loop-invariant (the Philox key schedule of the unstick draw, comparisons of its
-    // parameters, the spills they cause: ~280 instructions and eight scalar waits in the ISA) is hoisted into the
-    // loop's preheader, and with the check inside the loop that preheader ran before every frozen step's first load.
-    const int e_first = blockIdx.x * kEnvsPerWave;
-    if (e_first >= A.ns.n_envs) return;
-    int flags_first = 0;
-    bool solve_first = false;
-    if (lane < kEnvsPerWave && e_first + lane < A.ns.n_envs) solve_first = noma_pre_env(A, e_first + lane, flags_first);
-    const unsigned todo_first = (unsigned)__ballot(solve_first);
-    if (todo_first == 0 && (long long)e_first + (long long)gridDim.x * kEnvsPerWave >= A.ns.n_envs) return;
-    for (int e0 = e_first; e0 < A.ns.n_envs; e0 += gridDim.x * kEnvsPerWave) {
-    int my_flags = flags_first;
-    bool my_solve = solve_first;
-    unsigned todo = todo_first;
-    if (e0 != e_first) {
-        my_flags = 0;
-        my_solve = false;
-        if (lane < kEnvsPerWave && e0 + lane < A.ns.n_envs) my_solve = noma_pre_env(A, e0 + lane, my_flags);
-        todo = (unsigned)__ballot(my_solve);
+    long long t_acc[kStamps] = {}, t_last = 0;
+#define RISVEC_TICK(i)                                                      \
+    if constexpr (STAMP) {                                                  \
+        const long long now = (long long)__builtin_amdgcn_s_memtime();      \
+        t_acc[i] += now - t_last;                                           \
+        t_last = now;                                                       \
     }
-    if (todo == 0) continue;                           // all of the group's envs frozen
-    if (!tables_ready) {
-    tables_ready = true;
-    // Only the (rare) wavefronts that solve anything need the tables below; the opaque move keeps the compiler
-    // from hoisting their arithmetic into a prologue every frozen-step wavefront would then pay for.
-    int tl = lane;
-    asm volatile("" : "+v"(tl));
-    // binomials C(c, i) and their prefix sums over i (Pascal rows; one row per lane)
-    if (tl < 16) {
-        int c = 1;                                     // C(lane, 0)
-        int off = 0;
-        for (int i = 0; i <= kBinW; ++i) {
-            if (i < kBinW) s_binom[tl * kBinW + i] = c;
-            s_sizeoff[tl * (kBinW + 1) + i] = off;
-            off += c;
-            c = i < tl ? c * (tl - i) / (i + 1) : 0;       // C(lane, i+1)
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < EPL; ++t) {
-        const int idx = tl + t * kWave;
-        ein[t] = idx < NN;
-        ei[t] = ein[t] ? idx / N : 0;
-        ej[t] = ein[t] ? idx % N : 0;
-    }
-    if constexpr (kRanked) {                           // ranked table index: only beyond 2^KPLAIN masks
-        __syncthreads();
-        for (int b = lane; b < 256; b += kWave) {      // sum over set bits c_1 < c_2 < ... of C(c_i, i)
-            int r = 0, i = 1;
-            for (unsigned m = b; m; m &= m - 1, ++i) r += i < kBinW ? s_binom[(__ffs(m) - 1) * kBinW + i] : 0;
-            s_clo[b] = (uint16_t)r;
-        }
-        for (int e = lane; e < 9 * 128; e += kWave) {  // bits 8.. (positions 8 + c), ranks continue at p + 1
-            const int p = e / 128;
-            int r = 0, i = p + 1;
-            for (unsigned m = e % 128; m; m &= m - 1, ++i) r += i < kBinW ? s_binom[(8 + __ffs(m) - 1) * kBinW + i] : 0;
-            s_chi[e] = (uint16_t)r;
-        }
-    }
-    }   // tables
-    for (; todo; todo &= todo - 1) {
-        const int slot = __ffs(todo) - 1;
-        const int env = e0 + slot;
+    Deferred* const deferred_list = static_cast<Deferred*>(A.scratch);
+    // One env's pairing, all 64 lanes.  (A lambda with a single call site per instantiation: MODE 0 calls it for the envs its
+    // bookkeeping lanes flagged, MODE 1 for the envs MODE 0 left in the list.)
+    const auto solve_env = [&](const int env, const int flags) {
+        if constexpr (STAMP) { t_last = (long long)__builtin_amdgcn_s_memtime(); t_acc[11] += 1; }
         __syncthreads();                               // LDS reuse across envs
-        const int flags = __shfl(my_flags, slot, kWave);
         const int pend = A.ns.pending[env];
         const bool had_groups = (flags & RISVEC_NOMA_HAS_GROUPS) != 0;
         float* hist = A.ns.hist + (long long)env * NN;
@@ -413,6 +678,12 @@ k_noma_group(NomaArgs A) {
             if (pend > 0) streak = s_part[lane] >= 0 ? 0 : streak + pend;
         }
         if (P.qos_enable) {                            // TRAIN:1426-1441 + 858-880
+            // log2(y) >= R_min is y >= 2^R_min except within rounding of the boundary: only a y inside the +-1e-9 band
+            // around it (never, in practice) pays for the float64 log2 -- which was a tenth of a solve
+            const auto rate_ok = [&](double sinr) {
+                const double y = 1.0 + fmax(0.0, sinr);
+                return y >= A.qos_y_hi || (y > A.qos_y_lo && log2(y) >= P.qos_R_min);
+            };
 #pragma unroll
             for (int t = 0; t < EPL; ++t) {
                 if (!ein[t]) continue;
@@ -426,11 +697,12 @@ k_noma_group(NomaArgs A) {
                     const double pn = inear ? pi : pj, pf = inear ? pj : pi;
                     const double sf = (pf * gf) / (pn * gf + P.noise_power + 1e-12);
                     const double sn = (pn * gn) / (P.noise_power + 1e-12);
-                    okq = log2(1.0 + fmax(0.0, sf)) >= P.qos_R_min && log2(1.0 + fmax(0.0, sn)) >= P.qos_R_min;
+                    okq = rate_ok(sf) && rate_ok(sn);
                 }
                 s_qos[lane + t * kWave] = okq;
             }
         }
+        RISVEC_TICK(0)                                 // loads, history replay, QoS
         // ================= solve (TRAIN:1419-1524) ==================================================
         const int target = max(1, P.min_pair_target);
         double accept_q = P.mwm_accept_quantile;
@@ -439,6 +711,7 @@ k_noma_group(NomaArgs A) {
         unsigned busy = 0;                             // wave-uniform: users already paired
         unsigned long long mate = 0;                   // 4 bits per user, valid where busy
         int rounds = 0, npairs = 0, K_last = 0;
+        bool deferred = false;
         while (true) {
             // ---- score matrix (TRAIN:164-194) ---------------------------------------------------
             bool any_ok = false;
@@ -449,121 +722,180 @@ k_noma_group(NomaArgs A) {
                 any_ok = any_ok || (s_feas[lane + t * kWave] && abs_ok);
             }
             any_ok = __any(any_ok);
+            using RK = std::conditional_t<BIG, Sorted4, Ranks<EPL>>;
+            RK R;
+            int mine = 0;
+            double Sv[EPL];                            // this lane's scores
+            if constexpr (BIG) {                       // targets of the graph-gathering atomics below
+                if (lane < kNV) s_adj[lane] = 0;
+                if (lane == kNV) s_live[0] = 0;
+            }
 #pragma unroll
             for (int t = 0; t < EPL; ++t) {
-                if (!ein[t]) continue;
-                const int idx = lane + t * kWave, i = ei[t], j = ej[t];
-                const double gap = fabs(s_g[i] - s_g[j]);
-                const bool abs_ok = !any_ok || s_g[i] >= P.abs_gain_min_db || s_g[j] >= P.abs_gain_min_db;
-                const float hterm = P.score_w_history * s_hist[idx];       // float32 product
-                double Sv = P.score_w_delta_db * gap + (double)hterm;
-                if (!(s_feas[idx] && abs_ok)) Sv = -kInf;
-                if (P.qos_enable && !s_qos[idx] && finite(Sv)) Sv = Sv - P.qos_soft_penalty;
-                if (i == j) Sv = -kInf;
-                s_S[idx] = Sv;
-                s_R[idx] = finite(Sv) ? Sv : kInf;     // finite <=> (feasible > 0) & isfinite(S)
+                double Rv = kInf;                      // finite <=> (feasible > 0) & isfinite(S); +inf ranks after everything
+                Sv[t] = -kInf;
+                if (ein[t]) {
+                    const int idx = lane + t * kWave, i = ei[t], j = ej[t];
+                    const double gap = fabs(s_g[i] - s_g[j]);
+                    const bool abs_ok = !any_ok || s_g[i] >= P.abs_gain_min_db || s_g[j] >= P.abs_gain_min_db;
+                    const float hterm = P.score_w_history * s_hist[idx];       // float32 product
+                    double sv = P.score_w_delta_db * gap + (double)hterm;
+                    if (!(s_feas[idx] && abs_ok)) sv = -kInf;
+                    if (P.qos_enable && !s_qos[idx] && finite(sv)) sv = sv - P.qos_soft_penalty;
+                    if (i == j) sv = -kInf;
+                    s_S[idx] = sv;
+                    Sv[t] = sv;
+                    if (finite(sv)) { Rv = sv; ++mine; }
+                    if constexpr (!BIG) s_R[idx] = Rv;
+                }
+                if constexpr (BIG) R.v[t] = Rv;
             }
             __syncthreads();
-            Ranks<EPL> R;
-            rank_entries<EPL>(s_R, NN, lane, R);
+            if constexpr (BIG) {
+                sort256(R.v, lane);
+                R.cnt = wave_sum(mine);
+            } else {
+                rank_entries<EPL>(s_R, NN, lane, R);
+            }
             busy = 0; mate = 0; npairs = 0; K_last = 0;
+            RISVEC_TICK(1)                             // scores, ranks
             if (R.cnt > 0) {
                 // ---- primary matching (TRAIN:326-398) -----------------------------------------------
                 const double q = fmin(fmax(accept_q, 0.0), 1.0);
-                const double thr = quantile_linear<EPL>(R, 1.0 - q);
+                const double thr = quantile_linear(R, 1.0 - q);
+                // W = S where it reaches the threshold, -inf elsewhere; users without an edge drop out (singles allowed);
+                // the rest, in increasing order, are the matcher's users 0..K-1
+                if constexpr (!BIG) {
 #pragma unroll
-                for (int t = 0; t < EPL; ++t) {
-                    if (!ein[t]) continue;
-                    const int idx = lane + t * kWave;
-                    s_W[idx] = (finite(s_S[idx]) && s_S[idx] >= thr) ? s_S[idx] : -kInf;
-                }
-                __syncthreads();
-                bool has_edge = false;
-                if (lane < N)
-                    for (int u = 0; u < N; ++u)
-                        if (u != lane) has_edge = has_edge || finite(s_W[min(lane, u) * N + max(lane, u)]);
-                const unsigned live = (unsigned)__ballot(singles ? has_edge : lane < N) & 0xFFFFu;
-                const int K = __popc(live);
-                K_last = K;
-                if (K > 0) {
-                    // compressed weights w[a][b], a < b (users in increasing order); table layout
-                    for (int idx = lane; idx < K * K; idx += kWave) {
-                        const int a = idx / K, b = idx % K;
-                        unsigned m = live;
-                        int va = 0, vb = 0;
-                        for (int c = 0; m; m &= m - 1, ++c) {
-                            const int pos = __ffs(m) - 1;
-                            if (c == a) va = pos;
-                            if (c == b) vb = pos;
-                        }
-                        s_w[a * kNV + b] = a < b ? s_W[va * N + vb] : -kInf;
+                    for (int t = 0; t < EPL; ++t) {
+                        if (!ein[t]) continue;
+                        const int idx = lane + t * kWave;
+                        s_W[idx] = (finite(s_S[idx]) && s_S[idx] >= thr) ? s_S[idx] : -kInf;
                     }
                     __syncthreads();
-                    if (lane < K) {                             // admissible partners above each user
-                        int bits = 0;
-                        for (int b = lane + 1; b < K; ++b) bits |= finite(s_w[lane * kNV + b]) ? (1 << b) : 0;
-                        s_adj[lane] = bits;
-                    }
-                    if (lane == 0) {
-                        int off = 0;
-                        for (int x = 0; x < K; ++x) {
-                            s_base[x] = off;
-                            const int n = K - 1 - x;
-                            off += s_sizeoff[n * (kBinW + 1) + min(x, n) + 1];
-                        }
-                        s_base[K] = off;
-                    }
-                    __syncthreads();
-                    const MatchTab MT{s_dp, s_base, s_sizeoff, s_clo, s_chi, K, (1 << K) - 1, K <= S::KPLAIN};
-                    for (int x = K - 1; x >= 0; --x) {          // a state only needs states with a larger x
-                        const int n = K - 1 - x, low = (1 << x) - 1;
-                        for (int T = lane; T < (1 << n); T += kWave) {
-                            if (__popc(T) > x) continue;         // not reachable
-                            const int m = low | (T << (x + 1));
-                            int arg;
-                            const double b = best_at(MT, s_w, s_adj, singles, m, arg);
-                            const int sl = MT.slot(m);
-                            s_dp[sl] = arg == -2 ? 0.0 : b;            // TRAIN:389-390
-                            s_arg[sl] = (signed char)arg;
+                    bool has_edge = false;
+                    if (lane < N)
+                        for (int u = 0; u < N; ++u)
+                            if (u != lane) has_edge = has_edge || finite(s_W[min(lane, u) * N + max(lane, u)]);
+                    const unsigned live = (unsigned)__ballot(singles ? has_edge : lane < N) & 0xFFFFu;
+                    const int K = __popc(live);
+                    K_last = K;
+                    if (K > 0) {
+                        // compressed weights w[a][b], a < b
+                        for (int idx = lane; idx < K * K; idx += kWave) {
+                            const int a = idx / K, b = idx % K;
+                            unsigned m = live;
+                            int va = 0, vb = 0;
+                            for (int c = 0; m; m &= m - 1, ++c) {
+                                const int pos = __ffs(m) - 1;
+                                if (c == a) va = pos;
+                                if (c == b) vb = pos;
+                            }
+                            s_w[a * kNV + b] = a < b ? s_W[va * N + vb] : -kInf;
                         }
                         __syncthreads();
+                        if (lane < K) {                         // admissible partners above each user
+                            int bits = 0;
+                            for (int b = lane + 1; b < K; ++b) bits |= finite(s_w[lane * kNV + b]) ? (1 << b) : 0;
+                            s_adj[lane] = bits;
+                        }
+                        __syncthreads();
+                        RISVEC_TICK(2)
+                        const PlainTab MT{s_dp, s_arg, (1 << K) - 1};
+                        solve_plain(MT, s_w, s_adj, singles, K, lane);
+                        walk_choices(MT, live, busy, mate, npairs);
                     }
-                    // walk the choices from the empty mask (every lane, same reads)
-                    int m = 0;
-                    while (m != MT.full) {
-                        const int arg = s_arg[MT.slot(m)];
-                        if (arg == -2) break;
-                        const int x = __ffs(~m) - 1;
-                        m |= 1 << x;
-                        if (arg >= 0) {
-                            m |= 1 << arg;
-                            unsigned lm = live;
-                            int vx = 0, vj = 0;
-                            for (int c = 0; lm; lm &= lm - 1, ++c) {
-                                const int pos = __ffs(lm) - 1;
-                                if (c == x) vx = pos;
-                                if (c == arg) vj = pos;
+                } else {
+                    // every lane knows which of its own entries are edges (i < j, S >= thr): the users with an edge, the
+                    // compressed weights and the adjacency bits are gathered with LDS atomics instead of per-user scans
+                    unsigned mine_users = 0;
+                    bool edge[EPL];
+#pragma unroll
+                    for (int t = 0; t < EPL; ++t) {
+                        edge[t] = ein[t] && ei[t] < ej[t] && finite(Sv[t]) && Sv[t] >= thr;
+                        if (edge[t]) mine_users |= (1u << ei[t]) | (1u << ej[t]);
+                    }
+                    if (mine_users) atomicOr(&s_live[0], mine_users);
+                    __syncthreads();
+                    const unsigned live = singles ? s_live[0] : (N >= 32 ? ~0u : (1u << N) - 1u);
+                    const int K = __popc(live);
+                    K_last = K;
+                    if (K > 0) {
+#pragma unroll
+                        for (int t = 0; t < EPL; ++t) {
+                            if (!edge[t]) continue;
+                            const int a = __popc(live & ((1u << ei[t]) - 1u)), b = __popc(live & ((1u << ej[t]) - 1u));
+                            s_w[a * kNV + b] = Sv[t];
+                            atomicOr(&s_adj[a], 1 << b);
+                        }
+                        __syncthreads();
+                        RISVEC_TICK(2)                 // threshold, matchable users, compressed weights
+                        // layer x (lane x): its frontier, how many of it can be taken, where its states start
+                        unsigned meta = 0, adj_mine = 0;
+                        int size = 0;
+                        unsigned long long pw = 0;
+                        if (lane < K) {
+                            const unsigned above = ~((2u << lane) - 1u);
+                            unsigned acc = 0;
+                            int cap = 0;
+                            for (int xp = 0; xp < lane; ++xp) {
+                                const unsigned ax = (unsigned)s_adj[xp];
+                                acc |= ax;
+                                cap += (ax & above) ? 1 : 0;
                             }
-                            busy |= (1u << vx) | (1u << vj);
-                            mate |= ((unsigned long long)vj << (4 * vx)) | ((unsigned long long)vx << (4 * vj));
-                            ++npairs;
+                            adj_mine = (unsigned)s_adj[lane];
+                            const unsigned F = acc & above;
+                            const int nf = __popc(F);
+                            cap = min(cap, nf);
+                            const bool direct = nf <= 6;           // 2^6: one pass of the wavefront either way
+                            size = direct ? 1 << nf : colex->sizeoff[nf * (kBinW + 1) + cap + 1];
+                            meta = F | ((unsigned)nf << 16) | ((unsigned)cap << 20) | ((direct ? 1u : 0u) << 24);
+                            int r = 0;
+                            for (unsigned m = F; m; m &= m - 1, ++r) pw |= (unsigned long long)r << (4 * (__ffs(m) - 1));
+                        }
+                        int base = size;                           // exclusive prefix sum over the 16 lanes that matter
+#pragma unroll
+                        for (int o = 1; o <= kNV; o <<= 1) {
+                            const int up = __shfl_up(base, o, kWave);
+                            if (lane >= o) base += up;
+                        }
+                        base -= size;
+                        if (lane < K) s_layer[lane] = Layer{pw, base, meta};
+                        const int total = __shfl(base, K, kWave);  // lane K: everything below it
+                        __syncthreads();
+                        RISVEC_TICK(3)                 // frontiers
+                        const int full = (1 << K) - 1;
+                        if (MODE == 1 || total <= S::DP) {
+                            if constexpr (STAMP) t_acc[10] += 1;
+                            const FrontTab MT{s_dp, s_arg, s_layer, colex, full, total - 1};
+                            solve_frontier<MODE == 1>(MT, s_w, meta, base, adj_mine, singles, K, lane);
+                            RISVEC_TICK(4)             // table
+                            walk_choices(MT, live, busy, mate, npairs);
+                            RISVEC_TICK(5)             // walk
+                        } else {                       // too large for this launch's table: leave the env to the second one
+                            deferred = true;
                         }
                     }
                 }
+                RISVEC_TICK(2)
                 // ---- greedy completion (TRAIN:276-324) ----------------------------------------------
-                if (npairs < target) {
-                    const double thr2 = quantile_linear<EPL>(R, P.completion_min_quantile);
+                if (!deferred && npairs < target) {
+                    const double thr2 = quantile_linear(R, P.completion_min_quantile);
                     while (npairs < target) {
                         double bs = -kInf;
                         int bi = -1;
-#pragma unroll
-                        for (int t = 0; t < EPL; ++t) {
-                            if (!ein[t]) continue;
+                        // (unrolled by hand: `#pragma unroll` is refused for this loop in this nest, and a rolled loop
+                        // indexes ei / ej dynamically, which moves them -- for the whole kernel -- into scratch memory)
+                        const auto scan = [&](int t) {
+                            if (!ein[t]) return;
                             const int idx = lane + t * kWave, i = ei[t], j = ej[t];
                             const double s = s_S[idx];
                             if (i < j && finite(s) && s >= thr2 && !((busy >> i) & 1) && !((busy >> j) & 1))
                                 if (bi < 0 || s > bs || (s == bs && idx > bi)) { bs = s; bi = idx; }
-                        }
+                        };
+                        scan(0);
+                        if constexpr (EPL == 4) { scan(1); scan(2); scan(3); }
+                        static_assert(EPL == 1 || EPL == 4, "scan() calls above");
 #pragma unroll
                         for (int o = kWave / 2; o > 0; o >>= 1) {
                             const double os = __shfl_xor(bs, o, kWave);
@@ -578,6 +910,8 @@ k_noma_group(NomaArgs A) {
                     }
                 }
             }
+            RISVEC_TICK(6)                             // completion
+            if (deferred) break;
             // ---- back-off (TRAIN:1493-1524) ---------------------------------------------------------
             if (npairs >= target || rounds >= P.mwm_backoff_rounds) break;
             ++rounds;
@@ -600,8 +934,13 @@ k_noma_group(NomaArgs A) {
             }
             accept_q = fmax(0.05, accept_q - P.mwm_accept_q_step);
             __syncthreads();
+            RISVEC_TICK(7)                             // mask relaxation
         }
         __syncthreads();
+        if (deferred) {                                // nothing of this env has been written yet
+            if (lane == 0) deferred_list->env[atomicAdd(&deferred_list->count, 1)] = env;
+            return;
+        }
         // ---- episode_groups <- pairs + singles (TRAIN:1548-1553); history / streak (TRAIN:1556-1561) -----
         if (lane < N) {
             int p = -1;
@@ -631,19 +970,104 @@ k_noma_group(NomaArgs A) {
                 o[0] = 1; o[1] = rounds; o[2] = npairs; o[3] = K_last;
             }
         }
+        RISVEC_TICK(8)                                 // stores
+    };
+
+    if constexpr (MODE == 0) {
+    bool tables_ready = false;
+    // The common case -- a wavefront whose (only) env group is frozen -- is decided and LEAVES here, in front of the loop.
+    // Whatever the solve path keeps loop-invariant (the Philox key schedule of the unstick draw, comparisons of its
+    // parameters, the spills they cause: ~280 instructions and eight scalar waits in the ISA) is hoisted into the
+    // loop's preheader, and with the check inside the loop that preheader ran before every frozen step's first load.
+    const int e_first = blockIdx.x * kEnvsPerWave;
+    if (e_first >= A.ns.n_envs) return;
+    int flags_first = 0;
+    bool solve_first = false;
+    if (lane < kEnvsPerWave && e_first + lane < A.ns.n_envs) solve_first = noma_pre_env(A, e_first + lane, flags_first);
+    const unsigned todo_first = (unsigned)__ballot(solve_first);
+    if (todo_first == 0 && (long long)e_first + (long long)gridDim.x * kEnvsPerWave >= A.ns.n_envs) return;
+    for (int e0 = e_first; e0 < A.ns.n_envs; e0 += gridDim.x * kEnvsPerWave) {
+    int my_flags = flags_first;
+    bool my_solve = solve_first;
+    unsigned todo = todo_first;
+    if (e0 != e_first) {
+        my_flags = 0;
+        my_solve = false;
+        if (lane < kEnvsPerWave && e0 + lane < A.ns.n_envs) my_solve = noma_pre_env(A, e0 + lane, my_flags);
+        todo = (unsigned)__ballot(my_solve);
+    }
+    if (todo == 0) continue;                           // all of the group's envs frozen
+    if (!tables_ready) {
+    tables_ready = true;
+    // Only the (rare) wavefronts that solve anything need the index arithmetic below; the opaque move keeps the
+    // compiler from hoisting it into a prologue every frozen-step wavefront would then pay for.
+    int tl = lane;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int idx = tl + t * kWave;
+        ein[t] = idx < NN;
+        ei[t] = ein[t] ? idx / N : 0;
+        ej[t] = ein[t] ? idx % N : 0;
+    }
+    }   // tables
+    for (; todo; todo &= todo - 1) {
+        const int slot = __ffs(todo) - 1;
+        solve_env(e0 + slot, __shfl(my_flags, slot, kWave));
     }
     }   // 8-env groups
+    } else {
+        // second launch: the envs the first one left (their bookkeeping is done, nothing else of theirs was touched)
+        const int n_left = deferred_list->count;
+        if (n_left == 0) return;                       // nearly every call: nothing was left
+        {
+            const int* src = reinterpret_cast<const int*>(&kColex);
+            int* dst = reinterpret_cast<int*>(&s_colex);
+            for (int i = lane; i < (int)(sizeof(ColexTab) / 4); i += kWave) dst[i] = src[i];
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                const int idx = lane + t * kWave;
+                ein[t] = idx < NN;
+                ei[t] = ein[t] ? idx / N : 0;
+                ej[t] = ein[t] ? idx % N : 0;
+            }
+            for (int k = blockIdx.x; k < n_left; k += gridDim.x) {
+                const int env = deferred_list->env[k];
+                solve_env(env, (int)A.ns.flags[env]);
+            }
+        }
+        // the last block to get here empties the list for the next call (every block has read `count` by then)
+        __syncthreads();
+        if (lane == 0) {
+            __threadfence();
+            if (atomicAdd(&deferred_list->done, 1) == (int)gridDim.x - 1) {
+                deferred_list->count = 0;
+                deferred_list->done = 0;
+            }
+        }
+    }
+#undef RISVEC_TICK
+    if constexpr (STAMP) {
+        long long* out = A.stamps + ((size_t)MODE * kDeferredGridMax * 64 + blockIdx.x) * kStamps;
+        if (lane == 0 && (MODE == 1 || blockIdx.x < kDeferredGridMax * 64))
+            for (int i = 0; i < kStamps; ++i) out[i] = t_acc[i];
+    }
 }
 
 // tau = quantile q of |g_strong - g_weak| (TRAIN:842-855) and the feasibility mask (TRAIN:134-156).
+// The quantile is over strong x weak user pairs only -- at most 8 x 8 = 64 values -- so they are packed (by the
+// users' ranks, which are a permutation) into one value per lane before ranking: 64 x 64 compares instead of the
+// 256 x 256 the full matrix cost at 16 users.
 template <int NMAX>
 __global__ void __launch_bounds__(kWave)
 k_noma_mask(RisVecNomaState ns, const float* gain, const double* gdb15, double q_now, int K_now) {
-    constexpr int NNM = NMAX * NMAX, EPL = NNM / kWave;
-    __shared__ double s_g[kNV], s_d[NNM], s_R[NNM];
+    constexpr int NNM = NMAX * NMAX;
+    __shared__ double s_g[kNV], s_d[NNM], s_R[kWave];
+    __shared__ int s_rk[kNV];
     __shared__ uint8_t s_m[NNM], s_keep[NNM];
     const int lane = threadIdx.x;
     const int N = ns.n_veh, NN = N * N;
+    const int n_weak = N / 2, n_pairs = (N - n_weak) * n_weak;
     for (int env = blockIdx.x; env < ns.n_envs; env += gridDim.x) {
         __syncthreads();
         if (lane < N)
@@ -651,23 +1075,25 @@ k_noma_mask(RisVecNomaState ns, const float* gain, const double* gdb15, double q
                               : 10.0 * log10(fmax((double)gain[(long long)env * N + lane], 1e-15));
         __syncthreads();
         // weak half = the n/2 smallest (argsort, equal keys by index); diffs over strong x weak
+        if (lane < N) {
+            int r = 0;
+            for (int k = 0; k < N; ++k) r += (s_g[k] < s_g[lane] || (s_g[k] == s_g[lane] && k < lane)) ? 1 : 0;
+            s_rk[lane] = r;
+        }
+        __syncthreads();
         for (int idx = lane; idx < NN; idx += kWave) {
             const int i = idx / N, j = idx % N;
-            int ri = 0, rj = 0;
-            for (int k = 0; k < N; ++k) {
-                ri += (s_g[k] < s_g[i] || (s_g[k] == s_g[i] && k < i)) ? 1 : 0;
-                rj += (s_g[k] < s_g[j] || (s_g[k] == s_g[j] && k < j)) ? 1 : 0;
-            }
+            const int ri = s_rk[i], rj = s_rk[j];
             const double dgap = fabs(s_g[i] - s_g[j]);
             s_d[idx] = dgap;
-            s_R[idx] = (ri >= N / 2 && rj < N / 2) ? dgap : kInf;     // i strong, j weak
+            if (ri >= n_weak && rj < n_weak) s_R[(ri - n_weak) * n_weak + rj] = dgap;   // i strong, j weak
         }
         __syncthreads();
         double tau = 0.0;
         if (N >= 2) {
-            Ranks<EPL> R;
-            rank_entries<EPL>(s_R, NN, lane, R);
-            tau = quantile_linear<EPL>(R, q_now);
+            Ranks<1> R;
+            rank_entries<1>(s_R, n_pairs, lane, R);
+            tau = quantile_linear(R, q_now);
         }
         if (lane == 0) ns.tau[env] = tau;
         if (K_now < 1) continue;
@@ -709,6 +1135,25 @@ int noma_grid(int E) {
 
 }  // namespace
 
+// Blocks of k_noma_group's first launch (a wavefront each): one per EnvsPerWave envs, grid-stride beyond 2^20.
+long long noma_group_blocks(int n_envs, int n_veh) {
+    const int epw = n_veh <= 8 ? EnvsPerWave<8>::value : EnvsPerWave<16>::value;
+    const long long waves = ((long long)n_envs + epw - 1) / epw;
+    return waves < 1 ? 1 : (waves > (1 << 20) ? (1 << 20) : waves);
+}
+long long noma_stamp_bytes() {
+#ifdef RISVEC_DIAG
+    return (long long)(kDeferredGridMax * 64 + kDeferredGridMax) * kStamps * 8;
+#else
+    return 0;
+#endif
+}
+// Up to 8 vehicles: none.  Beyond: the list of envs the first launch leaves to the second (16 B header + one int per env).
+long long noma_scratch_bytes(int n_envs, int n_veh) {
+    if (n_veh <= 8) return 0;
+    return ((16 + 4LL * n_envs + 255) / 256) * 256 + noma_stamp_bytes();
+}
+
 hipError_t launch_noma_begin_episode(const RisVecNomaState& ns, hipStream_t st) {
     const size_t E = (size_t)ns.n_envs, N = (size_t)ns.n_veh;
     hipError_t err = hipMemsetAsync(ns.hist, 0, E * N * N * sizeof(float), st);
@@ -742,14 +1187,31 @@ hipError_t launch_noma_group(const RisVecNomaState& ns, const RisVecNomaParams& 
                              const double* tau_back, const float* prev_global, int prev_stride, int i_step,
                              const float* u_unstick, uint64_t seed, uint32_t counter, int32_t* info_out,
                              hipStream_t st) {
+    const double y = exp2(p.qos_R_min);                // TRAIN:870-871's log2(1 + sinr) >= R_min, see rate_ok
+    long long* stamps = nullptr;
+    if (noma_stamp_bytes() > 0 && ns.scratch)
+        stamps = reinterpret_cast<long long*>(static_cast<char*>(ns.scratch) + noma_scratch_bytes(ns.n_envs, ns.n_veh) - noma_stamp_bytes());
     NomaArgs a{ns, p, gain, gdb12, p01, p01_raw, use_mask, K_back, tau_back, prev_global, prev_stride, i_step,
-               u_unstick, seed, counter, info_out};
-    const int epw = ns.n_veh <= 8 ? EnvsPerWave<8>::value : EnvsPerWave<16>::value;
-    long long waves = ((long long)ns.n_envs + epw - 1) / epw;
-    if (waves > (1 << 20)) waves = 1 << 20;            // grid-stride beyond that
-    const dim3 grid((unsigned)waves);
-    if (ns.n_veh <= 8) hipLaunchKernelGGL((k_noma_group<8>), grid, dim3(kWave), 0, st, a);
-    else hipLaunchKernelGGL((k_noma_group<16>), grid, dim3(kWave), 0, st, a);
+               u_unstick, seed, counter, info_out, ns.scratch, stamps, y * (1.0 - 1e-9), y * (1.0 + 1e-9)};
+    const dim3 grid((unsigned)noma_group_blocks(ns.n_envs, ns.n_veh));
+    if (ns.n_veh <= 8) {
+        hipLaunchKernelGGL((k_noma_group<8>), grid, dim3(kWave), 0, st, a);
+        return hipGetLastError();
+    }
+    if (!ns.scratch || ns.scratch_bytes < noma_scratch_bytes(ns.n_envs, ns.n_veh)) return hipErrorInvalidValue;
+    // second launch: one wavefront per env the first one left (none on most steps: its blocks read the count and leave)
+    const long long want = ((long long)ns.n_envs + 31) / 32;
+    const dim3 grid2((unsigned)(want < kDeferredGridMax ? (want < 1 ? 1 : want) : kDeferredGridMax));
+#ifdef RISVEC_DIAG
+    static const char* want_stamps = std::getenv("RISVEC_NOMA_STAMPS");
+    if (want_stamps) {
+        hipLaunchKernelGGL((k_noma_group<16, 0, true>), grid, dim3(kWave), 0, st, a);
+        hipLaunchKernelGGL((k_noma_group<16, 1, true>), grid2, dim3(kWave), 0, st, a);
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL((k_noma_group<16, 0>), grid, dim3(kWave), 0, st, a);
+    hipLaunchKernelGGL((k_noma_group<16, 1>), grid2, dim3(kWave), 0, st, a);
     return hipGetLastError();
 }
 

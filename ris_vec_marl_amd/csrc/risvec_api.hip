@@ -480,6 +480,11 @@ void risvec_noma_default_params(RisVecNomaParams* p, int32_t n_veh) {
     p->pair_hist_decay = 0.97f;                                        // TRAIN:719
 }
 
+int64_t risvec_noma_scratch_bytes(int32_t n_envs, int32_t n_veh) {
+    if (n_envs < 1 || n_veh < 1 || n_veh > RISVEC_NOMA_MAX_VEH) return 0;
+    return risvec::noma_scratch_bytes(n_envs, n_veh);
+}
+
 static int check_noma(const char* fn, const RisVecNomaState* ns) {
     if (!ns) return fail(RISVEC_ERR_ARG, "%s: noma state is NULL", fn);
     if (ns->n_envs < 1) return fail(RISVEC_ERR_SHAPE, "%s: n_envs=%d must be >= 1", fn, ns->n_envs);
@@ -535,6 +540,11 @@ static int noma_group_impl(const char* fn, const RisVecNomaState* ns, const RisV
     if (prev_global && (reinterpret_cast<uintptr_t>(prev_global) & 3u))
         return fail(RISVEC_ERR_ARG, "%s: prev_global is not 4-byte aligned", fn);
     if (K_back < 0) return fail(RISVEC_ERR_ARG, "%s: K_back=%d must be >= 0", fn, K_back);
+    const long long need = risvec::noma_scratch_bytes(ns->n_envs, ns->n_veh);
+    if (need > 0 && (!ns->scratch || ns->scratch_bytes < need))
+        return fail(RISVEC_ERR_ARG, "%s: noma.scratch holds %lld bytes, risvec_noma_scratch_bytes(%d, %d) = %lld", fn,
+                    ns->scratch ? (long long)ns->scratch_bytes : 0LL, ns->n_envs, ns->n_veh, need);
+    if (need > 0) REQ_PTR(ns->scratch, "noma.scratch");
     if (np->mwm_backoff_rounds < 0 || np->mwm_backoff_rounds > 64)
         return fail(RISVEC_ERR_ARG, "%s: mwm_backoff_rounds=%d outside [0,64]", fn, np->mwm_backoff_rounds);
     return finish(fn, risvec::launch_noma_group(*ns, *np, gain, gdb12, p_off01, p01_raw, use_mask, K_back, tau_back,

@@ -44,6 +44,7 @@ hipError_t launch_sarl_step(const RisVecState& s, const RisVecSarlParams& p, con
                             const float* action_phase, const int32_t* arrivals, uint64_t seed,
                             uint32_t counter, uint32_t flags, hipStream_t st);
 
+long long noma_scratch_bytes(int n_envs, int n_veh);
 hipError_t launch_noma_begin_episode(const RisVecNomaState& ns, hipStream_t st);
 hipError_t launch_noma_mask(const RisVecNomaState& ns, const float* gain, const double* gdb15, double q_now,
                             int K_now, hipStream_t st);

@@ -191,6 +191,10 @@ class NomaGrouper:
         for k in ("hist", "streak", "partner", "n_groups", "last_global", "best_global", "flags", "mask", "tau",
                   "pending"):
             setattr(s, k, t[k].data_ptr())
+        n_scratch = int(N.load().risvec_noma_scratch_bytes(E, V))   # V > 8: the envs group()'s first launch leaves to its second
+        if n_scratch > 0:
+            t["scratch"] = torch.zeros(n_scratch, dtype=torch.uint8, device=dev)
+            s.scratch, s.scratch_bytes = t["scratch"].data_ptr(), n_scratch
         self._cstate = s
 
     def _stream(self) -> int:

@@ -228,6 +228,11 @@ def test_noma_and_replay_abi_without_a_gpu():
     assert lib.risvec_noma_group(C.byref(ns), C.byref(p), None, None, None, 0, 3, None, None, 1, 0, None, 0, 0, None,
                                  None) == N.ERR_ARG
     assert lib.risvec_noma_flush(C.byref(ns), None, None) == N.ERR_ARG
+    # scratch: none up to 8 vehicles; beyond, the list of envs the first launch leaves to the second (16 B + an int per env)
+    assert lib.risvec_noma_scratch_bytes(32768, 8) == 0
+    assert lib.risvec_noma_scratch_bytes(32768, 16) == 16 + 4 * 32768 + 240
+    assert lib.risvec_noma_scratch_bytes(17, 9) == 256
+    assert lib.risvec_noma_scratch_bytes(0, 16) == 0 and lib.risvec_noma_scratch_bytes(8, 17) == 0
     rb = N.RisVecReplay()
     assert lib.risvec_replay_store(C.byref(rb), 0, 1, None, None, None, 1, None, None, None, 0, None, None, None) \
         == N.ERR_SHAPE

@@ -230,6 +230,67 @@ def test_dense_matching_16_users():
         assert np.array_equal(partner[e], po), (e, partner[e], po)
 
 
+@pytest.mark.parametrize("N,q,singles,k_min", [
+    (16, 0.3, True, 9),        # sparse: narrow layers, first launch
+    (16, 0.5, True, 11),       # denser: wide (ranked) layers appear, some envs go to the second launch
+    (12, 1.0, True, 12),       # complete graph on 12: 377 states, second launch
+    (14, 1.0, False, 14),      # no singles
+    (15, 1.0, True, 15),
+    (16, 1.0, False, 16),      # the largest table there is (2 583 states)
+    (13, 0.6, False, 13),
+    (9, 1.0, True, 9),
+])
+def test_matching_table_forms_vs_oracle(N, q, singles, k_min):
+    """More than 8 users: the matching table is indexed by the frontier -- every subset of it for a narrow layer,
+    the subsets of at most cap(x) users ranked by (size, colex order) for a wide one; an env whose table exceeds
+    the first launch's 256 states is solved by the second.  Exact against the oracle's plain 2^K table in each
+    regime, two steps (so the history term of the second step's scores comes from the first step's pairs)."""
+    from ris_vec_marl_amd import NomaGrouper
+    E = 5
+    rng = np.random.default_rng(40 + N)
+    prm = NO.NomaParams(min_pair_target=N // 4, mwm_accept_quantile=q, mwm_allow_singles=singles, mask_enable=False,
+                        freeze_group_in_episode=False, mwm_backoff_rounds=1)
+    env = StubEnv(E, N, prm.noise_power, prm.P_max)
+    grouper = NomaGrouper(env, cfg_from(prm, N))
+    grouper.begin_episode(0)
+    eps = [NO.NomaEpisode(N) for _ in range(E)]
+    for t in range(2):
+        g = (10.0 ** rng.uniform(-11.8, -9.5, (E, N))).astype(np.float32)
+        gdb15 = NO.gain_db(g.astype(np.float64), 1e-15)
+        gdb12 = NO.gain_db(g.astype(np.float64), 1e-12)
+        partner, ng = grouper.group(None, t, gain=T(g), gdb12=T(gdb12), gdb15=T(gdb15))
+        partner = partner.cpu().numpy()
+        info = grouper.info.cpu().numpy()
+        assert int(info[:, 3].max()) >= k_min, info[:, 3]
+        for e in range(E):
+            groups, inf = NO.group_step(eps[e], g[e].astype(np.float64), np.zeros(N), None, prm, 0, t, gdb15=gdb15[e],
+                                        gdb12=gdb12[e])
+            po, ngo = NO.partner_of_groups(groups, N)
+            assert np.array_equal(partner[e], po), (t, e, partner[e], po)
+            assert ng.cpu().numpy()[e] == ngo and info[e, 2] == inf["n_pairs"]
+    assert np.array_equal(grouper.pair_affinity_hist.cpu().numpy(), np.stack([x.hist for x in eps]))
+
+
+def test_group_needs_its_scratch_beyond_8_vehicles():
+    """The C entry point refuses a 16-vehicle state without (enough) scratch instead of launching."""
+    from ris_vec_marl_amd import NomaGrouper, _native as NV
+    import ctypes as C
+    prm = NO.NomaParams()
+    env = StubEnv(32, 16, prm.noise_power, prm.P_max)
+    grouper = NomaGrouper(env, cfg_from(prm, 16))
+    grouper.begin_episode(0)
+    g = T(random_gains(np.random.default_rng(0), 32, 16))
+    grouper.group(None, 0, gain=g)                     # fine as built
+    st = grouper._cstate
+    keep = st.scratch_bytes
+    assert keep == NV.load().risvec_noma_scratch_bytes(32, 16) == 256
+    st.scratch_bytes = keep - 1
+    with pytest.raises(ValueError, match="scratch"):
+        grouper.group(None, 1, gain=g)
+    st.scratch_bytes = keep
+    grouper.group(None, 1, gain=g)
+
+
 def test_full_size_properties_and_step_consumes_groups():
     """E = 32 768 (BASELINE config 3 batch): every env's output is a valid grouping (symmetric
     partners, first/second listing by index, n_groups = N - pairs, at least min(target, feasible)
