@@ -69,7 +69,7 @@ struct NomaArgs {
     int32_t* info_out;
     void* scratch;               // Deferred (more than 8 users): the envs the first launch leaves to the second
     long long* stamps;           // diagnostic build only
-    double qos_y_lo, qos_y_hi;   // 2^qos_R_min -/+ 1e-9 relative: outside this band log2(y) >= R_min is decided without the log2
+    double qos_s_lo, qos_s_hi;   // (2^qos_R_min - 1) -/+ a 1e-9 band: outside it log2(1 + sinr) >= R_min is decided by a product
 };
 
 __device__ __forceinline__ double wave_max(double x) {
@@ -678,11 +678,15 @@ k_noma_group(NomaArgs A) {
             if (pend > 0) streak = s_part[lane] >= 0 ? 0 : streak + pend;
         }
         if (P.qos_enable) {                            // TRAIN:1426-1441 + 858-880
-            // log2(y) >= R_min is y >= 2^R_min except within rounding of the boundary: only a y inside the +-1e-9 band
-            // around it (never, in practice) pays for the float64 log2 -- which was a tenth of a solve
-            const auto rate_ok = [&](double sinr) {
-                const double y = 1.0 + fmax(0.0, sinr);
-                return y >= A.qos_y_hi || (y > A.qos_y_lo && log2(y) >= P.qos_R_min);
+            // log2(1 + num/den) >= R_min is num >= (2^R_min - 1) den except within rounding of the boundary: only a pair inside
+            // a +-1e-9 band around it (never, in practice) pays for the float64 division and log2 -- a fifth of a solve with
+            // the QoS check on
+            const auto rate_ok = [&](double num, double den) {
+                num = fmax(num, 0.0);                  // (the reference clamps the ratio; den > 0)
+                if (num >= A.qos_s_hi * den) return true;
+                if (num < A.qos_s_lo * den) return false;
+                const double y = 1.0 + fmax(0.0, num / den);
+                return log2(y) >= P.qos_R_min;
             };
 #pragma unroll
             for (int t = 0; t < EPL; ++t) {
@@ -695,9 +699,7 @@ k_noma_group(NomaArgs A) {
                     const bool inear = gi >= gj;
                     const double gn = inear ? gi : gj, gf = inear ? gj : gi;
                     const double pn = inear ? pi : pj, pf = inear ? pj : pi;
-                    const double sf = (pf * gf) / (pn * gf + P.noise_power + 1e-12);
-                    const double sn = (pn * gn) / (P.noise_power + 1e-12);
-                    okq = rate_ok(sf) && rate_ok(sn);
+                    okq = rate_ok(pf * gf, pn * gf + P.noise_power + 1e-12) && rate_ok(pn * gn, P.noise_power + 1e-12);
                 }
                 s_qos[lane + t * kWave] = okq;
             }
@@ -1187,12 +1189,14 @@ hipError_t launch_noma_group(const RisVecNomaState& ns, const RisVecNomaParams& 
                              const double* tau_back, const float* prev_global, int prev_stride, int i_step,
                              const float* u_unstick, uint64_t seed, uint32_t counter, int32_t* info_out,
                              hipStream_t st) {
-    const double y = exp2(p.qos_R_min);                // TRAIN:870-871's log2(1 + sinr) >= R_min, see rate_ok
+    // TRAIN:870-871's log2(1 + sinr) >= R_min, see rate_ok: sinr >= s_hi certainly passes, sinr < s_lo certainly fails
+    const double y = exp2(p.qos_R_min);
+    const double s_hi = y * (1.0 + 1e-9) - 1.0 + 1e-9, s_lo = y * (1.0 - 1e-9) - 1.0 - 1e-9;
     long long* stamps = nullptr;
     if (noma_stamp_bytes() > 0 && ns.scratch)
         stamps = reinterpret_cast<long long*>(static_cast<char*>(ns.scratch) + noma_scratch_bytes(ns.n_envs, ns.n_veh) - noma_stamp_bytes());
     NomaArgs a{ns, p, gain, gdb12, p01, p01_raw, use_mask, K_back, tau_back, prev_global, prev_stride, i_step,
-               u_unstick, seed, counter, info_out, ns.scratch, stamps, y * (1.0 - 1e-9), y * (1.0 + 1e-9)};
+               u_unstick, seed, counter, info_out, ns.scratch, stamps, s_lo, s_hi};
     const dim3 grid((unsigned)noma_group_blocks(ns.n_envs, ns.n_veh));
     if (ns.n_veh <= 8) {
         hipLaunchKernelGGL((k_noma_group<8>), grid, dim3(kWave), 0, st, a);
