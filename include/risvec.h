@@ -417,7 +417,7 @@ typedef struct RisVecNomaState {
 } RisVecNomaState;
 
 /* Scratch risvec_noma_group needs for this batch: 0 up to 8 vehicles, 16 B + 4 B per env (rounded up to 256 B) beyond.
- * Zero it once when it is allocated; every call leaves it zeroed. */
+ * Zero it once when it is allocated (risvec_noma_begin_episode also empties the list); every call leaves it empty. */
 int64_t risvec_noma_scratch_bytes(int32_t n_envs, int32_t n_veh);
 
 void risvec_noma_default_params(RisVecNomaParams *p, int32_t n_veh);   /* driver Config defaults */

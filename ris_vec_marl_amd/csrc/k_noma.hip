@@ -940,7 +940,10 @@ k_noma_group(NomaArgs A) {
         }
         __syncthreads();
         if (deferred) {                                // nothing of this env has been written yet
-            if (lane == 0) deferred_list->env[atomicAdd(&deferred_list->count, 1)] = env;
+            if (lane == 0) {
+                const int k = atomicAdd(&deferred_list->count, 1);
+                if (k < A.ns.n_envs) deferred_list->env[k] = env;      // (always, on a list that started empty)
+            }
             return;
         }
         // ---- episode_groups <- pairs + singles (TRAIN:1548-1553); history / streak (TRAIN:1556-1561) -----
@@ -1020,8 +1023,8 @@ k_noma_group(NomaArgs A) {
     }   // 8-env groups
     } else {
         // second launch: the envs the first one left (their bookkeeping is done, nothing else of theirs was touched)
-        const int n_left = deferred_list->count;
-        if (n_left == 0) return;                       // nearly every call: nothing was left
+        const int n_left = min(deferred_list->count, A.ns.n_envs);
+        if (n_left <= 0) return;                       // nearly every call: nothing was left
         {
             const int* src = reinterpret_cast<const int*>(&kColex);
             int* dst = reinterpret_cast<int*>(&s_colex);
@@ -1164,6 +1167,10 @@ hipError_t launch_noma_begin_episode(const RisVecNomaState& ns, hipStream_t st) 
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(ns.pending, 0, E * sizeof(int32_t), st);
     if (err != hipSuccess) return err;
+    if (ns.scratch && ns.scratch_bytes >= (long long)sizeof(Deferred)) {       // the (empty) list of the two-launch scheme
+        err = hipMemsetAsync(ns.scratch, 0, sizeof(Deferred), st);
+        if (err != hipSuccess) return err;
+    }
     return hipMemsetAsync(ns.flags, 0, E, st);
 }
 
