@@ -40,5 +40,8 @@ for name, yaml in (("driver-default", False), ("config.yaml", True)):
     out["share"] = {n: round(float(v) / tot, 3) for n, v in zip(NAMES[:10], med[:10])}
     print(json.dumps(dict(config=name, E=E, V=V, blocks=int(raw.shape[0]), second_launch_envs=int(second[:, 11].sum()),
                           second_launch_ticks_per_solve=float(np.median(second[:, :10].sum(axis=1) / second[:, 11])) if len(second) else 0.0,
-                          max_block_ticks=float(raw[:, :10].sum(axis=1).max()), ticks_per_block=tot,
+                          max_block_ticks=float(raw[:, :10].sum(axis=1).max()),
+                          block_ticks_mean=float(raw[:, :10].sum(axis=1).mean()),
+                          block_ticks_percentiles_10_50_90_99=[float(x) for x in np.percentile(raw[:, :10].sum(axis=1), [10, 50, 90, 99])],
+                          ticks_per_block=tot,
                           ticks_per_solve=tot / max(1.0, float(med[11])), **out)))

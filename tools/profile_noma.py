@@ -37,10 +37,13 @@ def timed(fn, n):
     return a.elapsed_time(b) * 1e3 / n
 
 
-for name, yaml in (("driver-default", False), ("config.yaml", True)):
+CASES = [("driver-default", False), ("config.yaml", True)]
+if os.environ.get("NOMA_PROFILE_NO_QOS"):
+    CASES.append(("config.yaml without the QoS check", "noqos"))
+for name, yaml in CASES:
     g = NomaGrouper(env)
     if yaml:
-        g.config.apply_yaml({"min_pair_target": 3, "mwm_backoff_rounds": 3, "qos_enable": True,
+        g.config.apply_yaml({"min_pair_target": 3, "mwm_backoff_rounds": 3, "qos_enable": yaml != "noqos",
                              "reward": {"mask_topk_start": 7, "mask_topk_end": 7, "mask_tau_q_start": 0.10,
                                         "mask_tau_q_end": 0.25, "pairing_threshold_quantile": 0.25}})
     g.begin_episode(0)
