@@ -291,6 +291,54 @@ def test_group_needs_its_scratch_beyond_8_vehicles():
     grouper.group(None, 1, gain=g)
 
 
+def test_full_size_16_vehicles_is_independent_of_batching():
+    """32 768 envs x 16 vehicles on real channel gains (about 1 % of them with every gain at the floor, i.e. a complete
+    pairing graph): the same envs solved as one batch -- first launch, deferred list, second launch -- and in slices of
+    37 must give identical groups, histories and info, and a second run of the batch must repeat the first.  Which
+    wavefront solves an env, and in which launch, must not show."""
+    from ris_vec_marl_amd import NomaGrouper, VecEnviron, reference_lanes
+    E, V, M = 32768, 16, 16
+    L = reference_lanes()
+    env = VecEnviron(L["down_lanes"], L["up_lanes"], L["left_lanes"], L["right_lanes"], 400, 400, V, M, 3,
+                     n_envs=E, device=DEV, seed=5)
+    env.make_new_game(); env.renew_positions(); env.compute_parms(); env.Random_phase(); env.update_channel_gains()
+    gain = env.tensors["gain"].clone()
+    rng = np.random.default_rng(1)
+    p01 = torch.from_numpy(rng.uniform(0, 1, (E, V)).astype(np.float32)).to(DEV)
+
+    def run(g_t, p_t):
+        stub = StubEnv(g_t.shape[0], V, float(env.noise_power), float(env.P_max))
+        gr = NomaGrouper(stub)
+        gr.config.qos_enable = True
+        gr.begin_episode(0)
+        gr.refresh_mask(gain=g_t)
+        partner, ng = gr.group(p_t, 0, gain=g_t)
+        out = [partner.cpu().numpy().copy(), ng.cpu().numpy().copy(), gr.info.cpu().numpy().copy(),
+               gr.pair_affinity_hist.cpu().numpy().copy()]
+        left = int(gr._t["scratch"][:4].view(torch.int32)[0].item())
+        assert left == 0                                   # the second launch emptied the list
+        return out
+
+    whole = run(gain, p01)
+    again = run(gain, p01)
+    for a, b in zip(whole, again):
+        assert np.array_equal(a, b)
+    info = whole[2]
+    dense = np.flatnonzero(info[:, 3] >= 15)               # matchable users of the last matching
+    assert len(dense) >= 50, len(dense)                    # the second launch had work
+    part = whole[0]
+    busy = part >= 0
+    mate = np.where(busy, part & 0xFFFF, 0)
+    assert np.array_equal(np.take_along_axis(mate, mate, 1)[busy], np.broadcast_to(np.arange(V), part.shape)[busy])
+    assert np.array_equal(whole[1], V - busy.sum(1) // 2)
+    pick = np.unique(np.concatenate([dense[:40], rng.integers(0, E, 71), [0, E - 1]]))
+    for lo in range(0, len(pick), 37):
+        idx = torch.from_numpy(pick[lo:lo + 37]).to(DEV)
+        small = run(gain[idx].contiguous(), p01[idx].contiguous())
+        for a, b in zip(whole, small):
+            assert np.array_equal(a[pick[lo:lo + 37]], b), lo
+
+
 def test_full_size_properties_and_step_consumes_groups():
     """E = 32 768 (BASELINE config 3 batch): every env's output is a valid grouping (symmetric
     partners, first/second listing by index, n_groups = N - pairs, at least min(target, feasible)
