@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 from oracle import risvec_oracle as orc  # noqa: E402  (checker)
-from tests.test_hip_parity import (RT, c128, check_step, cpu, make_vec, put_complex, random_step_inputs, snap,  # noqa: E402
+from tests.test_hip_parity import (RT, c128, check_step, cpu, make_vec, put_complex, random_step_inputs, record, snap,  # noqa: E402
                                    step_mask)
 
 
@@ -72,7 +72,8 @@ def test_step_bcd_entry_vs_oracle(V, M, E, bound):
         assert env._colsum_valid and env._ssum_sweeps == expect_sweeps
         # (1) theta: same decisions as the oracle wherever float64 noise cannot flip one
         th1 = c128(t["theta"])
-        assert safe.mean() > 0.97
+        record("BCD decisions left out of the comparison (fraction; float64 margin below 1e-9)", 1.0 - safe.mean())
+        assert safe.mean() > 0.999
         err_th = np.abs(th1 - o_th)[safe]
         worst["theta"] = max(worst["theta"], float(err_th.max()))
         assert err_th.max() <= 1.5e-7
@@ -90,7 +91,7 @@ def test_step_bcd_entry_vs_oracle(V, M, E, bound):
         worst["gain"] = max(worst["gain"], float(np.max((np.abs(g_dev - gain) - floor) / gain)))
         # and against the oracle's own sweep result for envs whose whole sweep is safe
         env_safe = safe.all(axis=1)
-        assert env_safe.mean() > 0.5
+        assert env_safe.mean() > 0.999                                # (observed: every env)
         g_orc = orc.gain_free(o_th, h, b, cpu(t["dist_r"]).astype(np.float64))
         img_o = np.einsum("em,evm,m->ev", o_th, h, b)
         # dist_r is float32 on the device: pl carries 2.2 * 6e-8 of that
@@ -99,7 +100,8 @@ def test_step_bcd_entry_vs_oracle(V, M, E, bound):
         o = orc.step(Bq, Qq, g_dev, act, partner, ng, arrivals, p)
         near_qos, near_other = step_mask(o, partner, g_dev, Qq)
         okr = check_step(env, out, o, Bq, p, near_qos, near_other)
-        assert okr.mean() > 0.97
+        record("samples left out of the reward comparison (fraction; discontinuities of step())", 1.0 - okr.mean())
+        assert okr.mean() > 0.999
         rel = np.abs(cpu(out[0]) - o["reward"])[okr] / np.maximum(np.abs(o["reward"][okr]), 1e-3)
         worst["reward"] = max(worst["reward"], float(rel.max()))
 
@@ -745,12 +747,14 @@ def test_full_size_properties_c5():
         out = small.step(action[:n], partner[:n], ng[:n], None, fused=True, bcd=True)
         assert N.last_kernel() == "k_step_fused_lat<16,256,1>"
         th1 = c128(t["theta"])
-        assert safe.mean() > 0.97 and np.abs(th1 - o_th)[safe].max() <= 1.5e-7
+        record("BCD decisions left out of the comparison (fraction; float64 margin below 1e-9)", 1.0 - safe.mean())
+        assert safe.mean() > 0.999 and np.abs(th1 - o_th)[safe].max() <= 1.5e-7
         g_dev = cpu(t["gain"]).astype(np.float64)
         o = orc.step(Bq, Qq, g_dev, cpu(action[:n]).astype(np.float64), pnp[:n], gnp[:n], arrivals, p)
         near_qos, near_other = step_mask(o, pnp[:n], g_dev, Qq)
         okr = check_step(small, out, o, Bq, p, near_qos, near_other)
-        assert okr.mean() > 0.97
+        record("samples left out of the reward comparison (fraction; discontinuities of step())", 1.0 - okr.mean())
+        assert okr.mean() > 0.999
     for k in keys:
         assert torch.equal(small.tensors[k], got[k][:n]), k
     # checkpoint round trip at full size (the indices are re-derived from the restored theta)

@@ -82,6 +82,9 @@ WORST = {}
 
 def record(name, value):
     """Largest observed relative error per check, printed by pytest -s / on failure (the margin to the bar)."""
+    if "left out" in name:                              # exclusions are reported per test
+        import inspect
+        name = "%s [%s]" % (name, inspect.stack()[1].function)
     WORST[name] = max(WORST.get(name, 0.0), float(value))
     print("[parity margin] %s: %.3e (worst so far %.3e)" % (name, float(value), WORST[name]))
 
@@ -392,7 +395,8 @@ def test_step_golden(V, which):
     np.testing.assert_allclose(o["reward"], g["reward"], rtol=1e-12)
     near_qos, near_other = step_mask(o, g["partner"], g["gain"], g["mec_q0"])
     okr = check_step(env, out, o, g["data_buf0"], p, near_qos, near_other)
-    assert okr.mean() > 0.97
+    record("samples left out of the reward comparison (fraction; discontinuities of step())", 1.0 - okr.mean())
+    assert okr.mean() > 0.98                     # observed: 0.9818 on one fixture (backlogs cleared locally: the 0/0 share), >= 0.9974 on the rest
     # global reward + metrics for envs with no excluded vehicle
     env_ok = okr.all(axis=1)
     m = cpu(t["metrics"])[:, :14]
@@ -482,7 +486,8 @@ def test_fused_step_vs_oracle(V, M):
     o = orc.step(B0.astype(np.float64), Q0.astype(np.float64), g_dev, action.astype(np.float64), partner, ng, arrivals, p)
     near_qos, near_other = step_mask(o, partner, g_dev, Q0)
     okr = check_step(env, out, o, B0.astype(np.float64), p, near_qos, near_other)
-    assert okr.mean() > 0.97
+    record("samples left out of the reward comparison (fraction; discontinuities of step())", 1.0 - okr.mean())
+    assert okr.mean() > 0.999                    # observed: >= 0.99975
     env_ok = okr.all(axis=1)
     d_scale = (B0 * 1000.0 * p.cycles_per_bit / (p.cpu_share_floor * p.f_local_max)).mean(axis=1)
     err_g = np.abs(cpu(out[1]) - o["global_reward"])
@@ -547,7 +552,8 @@ def test_step_policy_action_flag():
     excl_r, excl_a = near_qos | near_qos32 | (o["viol"] != o32["viol"]), near_other | near_other32
     ok = ~excl_a
     okr = ok & ~excl_r
-    assert okr.mean() > 0.97
+    record("samples left out of the reward comparison (fraction; discontinuities of step())", 1.0 - okr.mean())
+    assert okr.mean() > 0.999                    # observed: >= 0.99975
     kb = np.maximum(B0.astype(np.float64), 1.0)
     d_scale = B0.astype(np.float64) * 1000 * p.cycles_per_bit / (p.cpu_share_floor * p.f_local_max)
     for key, dev, floor in (("vehicle_rate", in_kernel["rate"], 1e-7), ("data_t", in_kernel["data_t"], 1e-7),
@@ -874,7 +880,8 @@ def test_colsum_cache(V, M):
     o_th, o_idx = orc.bcd_sweep(snap(c128(th0), 3), c128(t["h_r"]), c128(t["b"]), np.ones((E, V)), 3)
     gap = orc.bcd_margin(snap(c128(th0), 3), c128(t["h_r"]), c128(t["b"]), 3)
     safe = np.minimum.accumulate(gap, axis=1) > 1e-9
-    assert safe.mean() > 0.98 and np.array_equal(i1[safe], o_idx[safe])
+    record("BCD decisions left out of the comparison (fraction; float64 margin below 1e-9)", 1.0 - safe.mean())
+    assert safe.mean() > 0.999 and np.array_equal(i1[safe], o_idx[safe])
 
 
 # ---------------------------------------------------------------------------- f1: SARL variant
@@ -1047,7 +1054,8 @@ def test_bcd_cached_sum_across_sweeps():
         o_th, o_idx = orc.bcd_sweep(th, h, b, np.ones((E, V)), 3)
         gap = orc.bcd_margin(th, h, b, 3)
         safe = np.minimum.accumulate(gap, axis=1) > 1e-9
-        assert safe.mean() > 0.98 and np.array_equal(idx[safe], o_idx[safe]), sweep
+        record("BCD decisions left out of the comparison (fraction; float64 margin below 1e-9)", 1.0 - safe.mean())
+        assert safe.mean() > 0.999 and np.array_equal(idx[safe], o_idx[safe]), sweep
         th = snap(c128(t["theta"]), 3)
         S = cpu(t["s_sum"]); S = S[:, 0] + 1j * S[:, 1]
         want = np.sum(th * (h.sum(axis=1) * b[None, :]), axis=1)
