@@ -66,6 +66,46 @@ def tstep_phase(name, E, V, M, T, launches, fused):
     print(json.dumps({"phase": name, "steps": T * launches, "identical_to_single_launches": True}), flush=True)
 
 
+def noma_phase(name, E, V, M, episodes, steps=100):
+    """Rollout with the device pairing stage: a full re-solve at the start of every episode, frozen steps in between, random
+    in-episode repairs (unstick draws from the device Philox stream); groups checked for consistency every episode."""
+    from ris_vec_marl_amd import NomaGrouper
+    rng = np.random.default_rng(4)
+    env = build_env(E, V, M, dev, 7, 0)
+    action = torch.from_numpy(rng.uniform(0, 1, (E, 2, V)).astype(np.float32)).to(dev)
+    p01 = action[:, 0, :].contiguous()
+    gr = NomaGrouper(env)
+    gr.config.freeze_unstick_prob = 0.002
+    gr.config.qos_enable = True
+    env.update_channel_gains()
+    gr.begin_episode(0); gr.refresh_mask()
+    partner, ng = gr.group(p01, 0)
+    step = env.bind_step(action, partner, ng, None, fused=True)
+    group = gr.bind_group(p01)
+    solved = 0
+    t0 = time.perf_counter()
+    for ep in range(episodes):
+        gr.begin_episode(ep); gr.refresh_mask()
+        gr.group(p01, 0)
+        for t in range(1, steps):
+            step()
+            group(t)
+        solved += int((gr._t["pending"] < steps - 1).sum().item())     # envs that re-solved inside the episode
+        step()
+        part = partner.cpu().numpy()
+        busy = part >= 0
+        mate = np.where(busy, part & 0xFFFF, 0)
+        assert np.array_equal(np.take_along_axis(mate, mate, 1)[busy], np.broadcast_to(np.arange(V), part.shape)[busy]), name
+        assert np.array_equal(ng.cpu().numpy(), V - busy.sum(1) // 2), name
+        if V > 8:
+            assert int(gr._t["scratch"][:4].view(torch.int32)[0].item()) == 0, name     # the second launch's list is empty
+        finite(env)
+    torch.cuda.synchronize()
+    assert solved > 0                                   # in-episode repairs happened
+    print(json.dumps({"phase": name, "steps": episodes * steps, "envs_that_resolved_inside_an_episode": solved,
+                      "us_per_step": round((time.perf_counter() - t0) / (episodes * steps) * 1e6, 2)}), flush=True)
+
+
 n = lambda x: max(10, int(x * scale))
 phase("headline fused 32768x8x64", 32768, 8, 64, n(4000))
 phase("configs[1] fused 4096x8x36", 4096, 8, 36, n(8000))
@@ -83,4 +123,7 @@ phase("reference default 16384x8x40", 16384, 8, 40, n(4000))
 tstep_phase("T-step fused 4096x8x36", 4096, 8, 36, 32, n(60), True)
 tstep_phase("T-step cached 2000x16x256", 2000, 16, 256, 25, n(40), False)
 tstep_phase("T-step fused fallback 700x6x50", 700, 6, 50, 8, n(30), True)
+noma_phase("pairing stage in the loop 32768x8x64", 32768, 8, 64, max(2, int(12 * scale)))
+noma_phase("pairing stage in the loop 8192x16x64 (two launches)", 8192, 16, 64, max(2, int(12 * scale)))
+noma_phase("pairing stage in the loop 1000x11x40", 1000, 11, 40, max(2, int(12 * scale)))
 print(json.dumps({"soak": "ok"}))
