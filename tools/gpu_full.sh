@@ -19,6 +19,7 @@ cd $R
 echo "== NOMA grouping timings" | tee -a $OUT/round_$TAG.log
 timeout -k 10 300 python tools/profile_noma.py 32768 8 > $OUT/noma_${TAG}_8.json 2>/dev/null; cat $OUT/noma_${TAG}_8.json
 timeout -k 10 300 python tools/profile_noma.py 32768 16 10 > $OUT/noma_${TAG}_16.json 2>/dev/null; cat $OUT/noma_${TAG}_16.json
+timeout -k 10 200 python tools/noma_stamps.py > $OUT/noma_stamps_$TAG.jsonl 2>/dev/null; cut -c1-300 $OUT/noma_stamps_$TAG.jsonl
 echo "== other configs" | tee -a $OUT/round_$TAG.log
 b() { NAME=$1; shift; timeout -k 10 400 python bench.py --no-cpu-baseline --no-legs "$@" > $OUT/bench_${TAG}_$NAME.json 2>/dev/null; python3 -c "import json,sys; d=json.load(open('$OUT/bench_${TAG}_$NAME.json')); print('$NAME: %.3e env-steps/s  %.1f us/step  frac %.3f' % (d['value'], d['ms_per_step']*1e3, d['roofline']['frac']))"; }
 b c2 --config c2
