@@ -229,6 +229,68 @@ k_colsum_slab(Dims d, const float* __restrict__ h_r, const float* __restrict__ b
     }
 }
 
+// k_colsum_rows256 (M = 256, the C5 shape): the same sums with every READ a whole 2-KiB vehicle row.  The slab kernel
+// above reads 128-byte pieces 2 KiB apart (one tile of 16 elements of every row of 64 envs) and reaches 4.5 TB/s on the
+// 1.07 GB of h_r at 32 768 x 16 x 256 -- the fused step kernel, which walks each env's 32 KiB front to back, reads the
+// same bytes at 6.5.  Here a wavefront does that walk: a row is 64 lanes x 32 bytes (four elements per lane), all rows
+// of the env in flight at once, float64 sums in registers; a workgroup covers 16 consecutive envs (8 wavefronts x 2)
+// and turns them into the lane-major cache through a [256][16] LDS tile, 256 bytes of every 1-KiB run.
+constexpr int kRowsM = 256, kRowsEnvs = 16, kRowsThreads = 8 * kWave, kRowsPad = kRowsEnvs + 1;
+
+template <int VU, bool NT>                                  // VU: vehicle rows a lane keeps in flight (VU >= V); NT: non-temporal loads
+__global__ void __launch_bounds__(kRowsThreads)
+k_colsum_rows256(Dims d, const float* __restrict__ h_r, const float* __restrict__ b, double* __restrict__ c_col) {
+    __shared__ double2 s_c[kRowsM * kRowsPad];              // 69 632 B
+    const int V = d.V, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const long long e_base = (long long)blockIdx.x * kRowsEnvs;
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(b) + 2 * lane;
+    const float4 bb0 = b4[0], bb1 = b4[1];                  // b of elements 4 lane .. 4 lane + 3
+    auto ld = [](const float4* src) {
+        if (NT) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src));
+            return make_float4(t.x, t.y, t.z, t.w);
+        }
+        return *src;
+    };
+#pragma unroll
+    for (int q = 0; q < kRowsEnvs / 8; ++q) {
+        const int el = wave * (kRowsEnvs / 8) + q;          // env inside the workgroup
+        long long e = e_base + el;
+        e = e < d.E ? e : d.E - 1;                          // tail: re-read the last env (never written)
+        const float4* __restrict__ row = reinterpret_cast<const float4*>(h_r) + e * V * (kRowsM / 2) + 2 * lane;
+        float4 h0[VU], h1[VU];
+#pragma unroll
+        for (int k = 0; k < VU; ++k) {
+            const float4* src = row + (long long)(k < V ? k : V - 1) * (kRowsM / 2);
+            h0[k] = ld(src);
+            h1[k] = ld(src + 1);
+        }
+        double s0r = 0.0, s0i = 0.0, s1r = 0.0, s1i = 0.0, s2r = 0.0, s2i = 0.0, s3r = 0.0, s3i = 0.0;
+#pragma unroll
+        for (int k = 0; k < VU; ++k) {
+            const bool ok = k < V;
+            s0r += ok ? (double)h0[k].x : 0.0; s0i += ok ? (double)h0[k].y : 0.0;
+            s1r += ok ? (double)h0[k].z : 0.0; s1i += ok ? (double)h0[k].w : 0.0;
+            s2r += ok ? (double)h1[k].x : 0.0; s2i += ok ? (double)h1[k].y : 0.0;
+            s3r += ok ? (double)h1[k].z : 0.0; s3i += ok ? (double)h1[k].w : 0.0;
+        }
+        double2* dst = s_c + (4 * lane) * kRowsPad + el;
+        dst[0 * kRowsPad] = make_double2(s0r * bb0.x - s0i * bb0.y, s0r * bb0.y + s0i * bb0.x);
+        dst[1 * kRowsPad] = make_double2(s1r * bb0.z - s1i * bb0.w, s1r * bb0.w + s1i * bb0.z);
+        dst[2 * kRowsPad] = make_double2(s2r * bb1.x - s2i * bb1.y, s2r * bb1.y + s2i * bb1.x);
+        dst[3 * kRowsPad] = make_double2(s3r * bb1.z - s3i * bb1.w, s3r * bb1.w + s3i * bb1.z);
+    }
+    __syncthreads();
+    // element (e, m) of the lane-major cache: ((e / 64) * M + m) * 64 + e % 64; the 16 envs of a workgroup share e / 64
+    double2* __restrict__ out = reinterpret_cast<double2*>(c_col) + (e_base >> 6) * kRowsM * kWave + (e_base & 63);
+#pragma unroll
+    for (int i = 0; i < kRowsM * kRowsEnvs / kRowsThreads; ++i) {
+        const int idx = threadIdx.x + i * kRowsThreads, m = idx / kRowsEnvs, el = idx % kRowsEnvs;
+        if (e_base + el < d.E) out[(long long)m * kWave + el] = s_c[m * kRowsPad + el];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // k_bcd_sweep
 // ---------------------------------------------------------------------------
@@ -744,7 +806,21 @@ k_bcd_sweep8_pair(Dims d, const double* __restrict__ c_col, float* __restrict__ 
 // launchers
 // ---------------------------------------------------------------------------
 hipError_t launch_colsum(const RisVecState& s, hipStream_t st) {
-    static const bool no_slab = std::getenv("RISVEC_NO_COLSUM_SLAB") != nullptr;       // A/B switch for experiments
+    static const bool no_slab = std::getenv("RISVEC_NO_COLSUM_SLAB") != nullptr;       // A/B switches for experiments
+    static const bool no_rows = std::getenv("RISVEC_NO_COLSUM_ROWS") != nullptr;
+    if (s.n_ris == kRowsM && s.n_veh <= 16 && !no_rows && !no_slab) {
+        static const char* nt_env = std::getenv("RISVEC_COLSUM_NT");              // "0" / "1" force it off / on (tests, A/B)
+        const bool nt = nt_env ? nt_env[0] == '1' : (long long)s.n_envs * s.n_veh * s.n_ris * 8 > tuning().colsum_nt_from;
+        const dim3 g((unsigned)(((long long)s.n_envs + kRowsEnvs - 1) / kRowsEnvs)), b(kRowsThreads);
+        if (s.n_veh <= 8) {
+            if (nt) hipLaunchKernelGGL((k_colsum_rows256<8, true>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+            else hipLaunchKernelGGL((k_colsum_rows256<8, false>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+        } else {
+            if (nt) hipLaunchKernelGGL((k_colsum_rows256<16, true>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+            else hipLaunchKernelGGL((k_colsum_rows256<16, false>), g, b, 0, st, dims_of(s), s.h_r, s.b, s.c_col);
+        }
+        return hipGetLastError();
+    }
     if (s.n_ris % kSlabM == 0 && s.n_veh <= 16 && !no_slab) {
         const long long blocks = ((long long)s.n_envs + kWave - 1) / kWave;
         if (blocks < (1LL << 31)) {
