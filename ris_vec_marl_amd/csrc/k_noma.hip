@@ -5,8 +5,8 @@
 // check (TRAIN:858-880) and the control logic with the freeze-in-episode safeties
 // (TRAIN:1401-1562, 1618-1623).
 //
-// Almost every step of an episode is a FROZEN step, so k_noma_group (one launch per group() call) is
-// built around that: a wavefront owns 8 consecutive envs; 8 lanes first do the per-env bookkeeping
+// Almost every step of an episode is a FROZEN step, so k_noma_group (one launch per group() call up to 8
+// users, two beyond: see Shape) is built around that: a wavefront owns 8 consecutive envs; 8 lanes first do the per-env bookkeeping
 // (reward tracking TRAIN:1618-1623, the freeze decision TRAIN:1527-1540); frozen envs only bump
 // `pending` -- the history decay / pair increments and streak updates they owe are replayed,
 // operation for operation, the next time somebody needs them (k_noma_flush for readers of those
@@ -337,7 +337,7 @@ __device__ __forceinline__ double quantile_linear(const RK& R, double q) {
     return r;
 }
 
-// ---- matching tables: value / choice of the recurrence at a mask, three ways of finding its slot -------------------
+// ---- matching tables: value / choice of the recurrence at a mask, two ways of finding its slot ---------------------
 // (compressed users 0..K-1; x = lowest unused user of the mask, T = the users taken above x)
 struct PlainTab {                                      // slot = mask
     double* dp;
@@ -411,7 +411,7 @@ __device__ __forceinline__ int rank_in_layer(const ColexTab* cx, unsigned meta, 
     return cx->sizeoff[nf * (kBinW + 1) + __popc(c)] + cx->clo[lo] + cx->chi[__popc(lo) * 128 + hi];
 }
 struct FrontTab {
-    double* dp;                                        // LDS, or the caller's scratch when the table is larger than Shape::DP
+    double* dp;                                        // LDS: Shape::DP entries (256 in the first launch, kTabMax in the second)
     signed char* arg;
     const Layer* layer;                                // [K]
     const ColexTab* colex;                             // constant memory, or the second launch's copy in LDS
