@@ -191,7 +191,7 @@ template <int NMAX, int MODE = 0>
 struct Shape {
     static constexpr int NN = NMAX * NMAX;
     static constexpr int EPL = NN / kWave;             // matrix entries per lane
-    static constexpr bool BIG = NMAX > 8;              // more than 8 users: sorted quantiles, frontier-indexed matching table
+    static constexpr bool BIG = NMAX > 8;              // more than 8 users: frontier-indexed matching table, second launch
     static constexpr int DP = !BIG ? 256 : (MODE == 0 ? 256 : kTabMax);   // LDS table entries (up to 8 users: the 2^8 masks)
 };
 // Scratch of the two-launch scheme: the envs MODE 0 left for MODE 1.
@@ -244,10 +244,12 @@ __device__ __forceinline__ double order_stat(const Ranks<EPL>& R, int k) {   // 
 // Bitonic network on element index e = 4 lane + t: the exchanges at distance 1 and 2 stay inside a lane, the
 // others pair lane with lane ^ (distance / 4).  Ranking 256 entries against each other took 2 x 256 float64
 // compares per entry (a third of a 16-user solve); this is 36 stages of one compare per entry.
-struct Sorted4 {
-    double v[4];
+template <int EPL>
+struct Sorted {
+    double v[EPL];
     int cnt;
 };
+using Sorted4 = Sorted<4>;
 __device__ __forceinline__ void cmpx(double& a, double& b, bool asc) {
     const bool sw = asc ? b < a : a < b;
     const double lo = sw ? b : a, hi = sw ? a : b;
@@ -307,6 +309,31 @@ __device__ __forceinline__ void sort256(double (&v)[4], int lane) {
     cmpx_lanes<1>(v, lane, true);
     cmpx_in_lane(v, true);
 }
+// 64 values, one per lane (up to 8 users), sorted ascending across the wavefront: 21 cross-lane stages.
+template <int D>
+__device__ __forceinline__ void cmpx_lane1(double& v, int lane, bool asc) {
+    const bool keep_min = ((lane & D) == 0) == asc;
+    const double other = __shfl_xor(v, D, kWave);
+    const bool take = keep_min ? other < v : v < other;
+    v = take ? other : v;
+}
+__device__ __forceinline__ void sort64(double& v, int lane) {
+    cmpx_lane1<1>(v, lane, (lane & 2) == 0);
+    bool asc = (lane & 4) == 0;
+    cmpx_lane1<2>(v, lane, asc); cmpx_lane1<1>(v, lane, asc);
+    asc = (lane & 8) == 0;
+    cmpx_lane1<4>(v, lane, asc); cmpx_lane1<2>(v, lane, asc); cmpx_lane1<1>(v, lane, asc);
+    asc = (lane & 16) == 0;
+    cmpx_lane1<8>(v, lane, asc); cmpx_lane1<4>(v, lane, asc); cmpx_lane1<2>(v, lane, asc); cmpx_lane1<1>(v, lane, asc);
+    asc = (lane & 32) == 0;
+    cmpx_lane1<16>(v, lane, asc); cmpx_lane1<8>(v, lane, asc); cmpx_lane1<4>(v, lane, asc); cmpx_lane1<2>(v, lane, asc);
+    cmpx_lane1<1>(v, lane, asc);
+    cmpx_lane1<32>(v, lane, true); cmpx_lane1<16>(v, lane, true); cmpx_lane1<8>(v, lane, true); cmpx_lane1<4>(v, lane, true);
+    cmpx_lane1<2>(v, lane, true); cmpx_lane1<1>(v, lane, true);
+}
+__device__ __forceinline__ double order_stat(const Sorted<1>& R, int k) { return __shfl(R.v[0], k, kWave); }
+__device__ __forceinline__ void sort_wave(Sorted<1>& R, int lane) { sort64(R.v[0], lane); }
+__device__ __forceinline__ void sort_wave(Sorted<4>& R, int lane) { sort256(R.v, lane); }
 __device__ __forceinline__ double order_stat(const Sorted4& R, int k) {       // k wave-uniform
     // (the four values pass through opaque moves: a select between loads of R.v[] is otherwise folded into ONE load at a
     // selected address, and an array indexed at run time lives in scratch memory)
@@ -606,7 +633,6 @@ k_noma_group(NomaArgs A) {
     constexpr int EPL = S::EPL;
     constexpr bool BIG = S::BIG;
     __shared__ double s_S[S::NN], s_w[kNV * kNV], s_g[kNV], s_lin[kNV], s_p[kNV];
-    __shared__ double s_R[BIG ? 1 : S::NN], s_W[BIG ? 1 : S::NN];   // (beyond 8 users: ranks by sorting, W read through s_S)
     __shared__ double s_dp[S::DP];
     __shared__ float s_hist[S::NN];
     __shared__ uint8_t s_feas[S::NN], s_qos[S::NN];
@@ -724,14 +750,11 @@ k_noma_group(NomaArgs A) {
                 any_ok = any_ok || (s_feas[lane + t * kWave] && abs_ok);
             }
             any_ok = __any(any_ok);
-            using RK = std::conditional_t<BIG, Sorted4, Ranks<EPL>>;
-            RK R;
+            Sorted<EPL> R;
             int mine = 0;
             double Sv[EPL];                            // this lane's scores
-            if constexpr (BIG) {                       // targets of the graph-gathering atomics below
-                if (lane < kNV) s_adj[lane] = 0;
-                if (lane == kNV) s_live[0] = 0;
-            }
+            if (lane < kNV) s_adj[lane] = 0;           // targets of the graph-gathering atomics below
+            if (lane == kNV) s_live[0] = 0;
 #pragma unroll
             for (int t = 0; t < EPL; ++t) {
                 double Rv = kInf;                      // finite <=> (feasible > 0) & isfinite(S); +inf ranks after everything
@@ -748,17 +771,12 @@ k_noma_group(NomaArgs A) {
                     s_S[idx] = sv;
                     Sv[t] = sv;
                     if (finite(sv)) { Rv = sv; ++mine; }
-                    if constexpr (!BIG) s_R[idx] = Rv;
                 }
-                if constexpr (BIG) R.v[t] = Rv;
+                R.v[t] = Rv;
             }
             __syncthreads();
-            if constexpr (BIG) {
-                sort256(R.v, lane);
-                R.cnt = wave_sum(mine);
-            } else {
-                rank_entries<EPL>(s_R, NN, lane, R);
-            }
+            sort_wave(R, lane);
+            R.cnt = wave_sum(mine);
             busy = 0; mate = 0; npairs = 0; K_last = 0;
             RISVEC_TICK(1)                             // scores, ranks
             if (R.cnt > 0) {
@@ -767,47 +785,7 @@ k_noma_group(NomaArgs A) {
                 const double thr = quantile_linear(R, 1.0 - q);
                 // W = S where it reaches the threshold, -inf elsewhere; users without an edge drop out (singles allowed);
                 // the rest, in increasing order, are the matcher's users 0..K-1
-                if constexpr (!BIG) {
-#pragma unroll
-                    for (int t = 0; t < EPL; ++t) {
-                        if (!ein[t]) continue;
-                        const int idx = lane + t * kWave;
-                        s_W[idx] = (finite(s_S[idx]) && s_S[idx] >= thr) ? s_S[idx] : -kInf;
-                    }
-                    __syncthreads();
-                    bool has_edge = false;
-                    if (lane < N)
-                        for (int u = 0; u < N; ++u)
-                            if (u != lane) has_edge = has_edge || finite(s_W[min(lane, u) * N + max(lane, u)]);
-                    const unsigned live = (unsigned)__ballot(singles ? has_edge : lane < N) & 0xFFFFu;
-                    const int K = __popc(live);
-                    K_last = K;
-                    if (K > 0) {
-                        // compressed weights w[a][b], a < b
-                        for (int idx = lane; idx < K * K; idx += kWave) {
-                            const int a = idx / K, b = idx % K;
-                            unsigned m = live;
-                            int va = 0, vb = 0;
-                            for (int c = 0; m; m &= m - 1, ++c) {
-                                const int pos = __ffs(m) - 1;
-                                if (c == a) va = pos;
-                                if (c == b) vb = pos;
-                            }
-                            s_w[a * kNV + b] = a < b ? s_W[va * N + vb] : -kInf;
-                        }
-                        __syncthreads();
-                        if (lane < K) {                         // admissible partners above each user
-                            int bits = 0;
-                            for (int b = lane + 1; b < K; ++b) bits |= finite(s_w[lane * kNV + b]) ? (1 << b) : 0;
-                            s_adj[lane] = bits;
-                        }
-                        __syncthreads();
-                        RISVEC_TICK(2)
-                        const PlainTab MT{s_dp, s_arg, (1 << K) - 1};
-                        solve_plain(MT, s_w, s_adj, singles, K, lane);
-                        walk_choices(MT, live, busy, mate, npairs);
-                    }
-                } else {
+                {
                     // every lane knows which of its own entries are edges (i < j, S >= thr): the users with an edge, the
                     // compressed weights and the adjacency bits are gathered with LDS atomics instead of per-user scans
                     unsigned mine_users = 0;
@@ -832,50 +810,56 @@ k_noma_group(NomaArgs A) {
                         }
                         __syncthreads();
                         RISVEC_TICK(2)                 // threshold, matchable users, compressed weights
-                        // layer x (lane x): its frontier, how many of it can be taken, where its states start
-                        unsigned meta = 0, adj_mine = 0;
-                        int size = 0;
-                        unsigned long long pw = 0;
-                        if (lane < K) {
-                            const unsigned above = ~((2u << lane) - 1u);
-                            unsigned acc = 0;
-                            int cap = 0;
-                            for (int xp = 0; xp < lane; ++xp) {
-                                const unsigned ax = (unsigned)s_adj[xp];
-                                acc |= ax;
-                                cap += (ax & above) ? 1 : 0;
-                            }
-                            adj_mine = (unsigned)s_adj[lane];
-                            const unsigned F = acc & above;
-                            const int nf = __popc(F);
-                            cap = min(cap, nf);
-                            const bool direct = nf <= 6;           // 2^6: one pass of the wavefront either way
-                            size = direct ? 1 << nf : colex->sizeoff[nf * (kBinW + 1) + cap + 1];
-                            meta = F | ((unsigned)nf << 16) | ((unsigned)cap << 20) | ((direct ? 1u : 0u) << 24);
-                            int r = 0;
-                            for (unsigned m = F; m; m &= m - 1, ++r) pw |= (unsigned long long)r << (4 * (__ffs(m) - 1));
-                        }
-                        int base = size;                           // exclusive prefix sum over the 16 lanes that matter
-#pragma unroll
-                        for (int o = 1; o <= kNV; o <<= 1) {
-                            const int up = __shfl_up(base, o, kWave);
-                            if (lane >= o) base += up;
-                        }
-                        base -= size;
-                        if (lane < K) s_layer[lane] = Layer{pw, base, meta};
-                        const int total = __shfl(base, K, kWave);  // lane K: everything below it
-                        __syncthreads();
-                        RISVEC_TICK(3)                 // frontiers
-                        const int full = (1 << K) - 1;
-                        if (MODE == 1 || total <= S::DP) {
-                            if constexpr (STAMP) t_acc[10] += 1;
-                            const FrontTab MT{s_dp, s_arg, s_layer, colex, full, total - 1};
-                            solve_frontier<MODE == 1>(MT, s_w, meta, base, adj_mine, singles, K, lane);
-                            RISVEC_TICK(4)             // table
+                        if constexpr (!BIG) {          // up to 8 users: the table indexed by the mask
+                            const PlainTab MT{s_dp, s_arg, (1 << K) - 1};
+                            solve_plain(MT, s_w, s_adj, singles, K, lane);
                             walk_choices(MT, live, busy, mate, npairs);
-                            RISVEC_TICK(5)             // walk
-                        } else {                       // too large for this launch's table: leave the env to the second one
-                            deferred = true;
+                        } else {
+                            // layer x (lane x): its frontier, how many of it can be taken, where its states start
+                            unsigned meta = 0, adj_mine = 0;
+                            int size = 0;
+                            unsigned long long pw = 0;
+                            if (lane < K) {
+                                const unsigned above = ~((2u << lane) - 1u);
+                                unsigned acc = 0;
+                                int cap = 0;
+                                for (int xp = 0; xp < lane; ++xp) {
+                                    const unsigned ax = (unsigned)s_adj[xp];
+                                    acc |= ax;
+                                    cap += (ax & above) ? 1 : 0;
+                                }
+                                adj_mine = (unsigned)s_adj[lane];
+                                const unsigned F = acc & above;
+                                const int nf = __popc(F);
+                                cap = min(cap, nf);
+                                const bool direct = nf <= 6;           // 2^6: one pass of the wavefront either way
+                                size = direct ? 1 << nf : colex->sizeoff[nf * (kBinW + 1) + cap + 1];
+                                meta = F | ((unsigned)nf << 16) | ((unsigned)cap << 20) | ((direct ? 1u : 0u) << 24);
+                                int r = 0;
+                                for (unsigned m = F; m; m &= m - 1, ++r) pw |= (unsigned long long)r << (4 * (__ffs(m) - 1));
+                            }
+                            int base = size;                           // exclusive prefix sum over the 16 lanes that matter
+    #pragma unroll
+                            for (int o = 1; o <= kNV; o <<= 1) {
+                                const int up = __shfl_up(base, o, kWave);
+                                if (lane >= o) base += up;
+                            }
+                            base -= size;
+                            if (lane < K) s_layer[lane] = Layer{pw, base, meta};
+                            const int total = __shfl(base, K, kWave);  // lane K: everything below it
+                            __syncthreads();
+                            RISVEC_TICK(3)                 // frontiers
+                            const int full = (1 << K) - 1;
+                            if (MODE == 1 || total <= S::DP) {
+                                if constexpr (STAMP) t_acc[10] += 1;
+                                const FrontTab MT{s_dp, s_arg, s_layer, colex, full, total - 1};
+                                solve_frontier<MODE == 1>(MT, s_w, meta, base, adj_mine, singles, K, lane);
+                                RISVEC_TICK(4)             // table
+                                walk_choices(MT, live, busy, mate, npairs);
+                                RISVEC_TICK(5)             // walk
+                            } else {                       // too large for this launch's table: leave the env to the second one
+                                deferred = true;
+                            }
                         }
                     }
                 }
