@@ -17,10 +17,11 @@
 // the lanes; every decision the reference takes by comparing float64 numbers is taken by comparing
 // float64 numbers formed in the same association order (fp contraction is off for the whole file:
 // the matcher's exact ties are decided by last-bit rounding, see EXPERIMENTS.md, section 8 f2).
-//   * quantiles: up to 8 users (64 entries, one per lane) each lane ranks its entry against all (LDS
-//     broadcast reads); beyond that (256 entries, four per lane) the wavefront sorts them with a
-//     bitonic network in registers (n^2 float64 compares were a third of a solve); either way the two
-//     order statistics NumPy's linear method interpolates are picked by rank;
+//   * quantiles: the wavefront sorts the scores with a bitonic network in registers (64 entries, one
+//     per lane, up to 8 users; 256 entries, four per lane, beyond: ranking every entry against all took
+//     n^2 float64 compares, a third of a 16-user solve) and the two order statistics NumPy's linear
+//     method interpolates are read by rank (the mask kernel's quantile is over at most 64 gaps, 16 of
+//     them at 8 users: there each lane still ranks its value against the others, which is cheaper);
 //   * matching: the reference's memoised recursion on the lowest unused user x, evaluated bottom-up
 //     in layers of x (a state only needs states with a larger x), after dropping users without any
 //     admissible edge (they pass the value through unchanged).  Only states the recursion can reach
