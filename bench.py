@@ -286,7 +286,8 @@ class Case:
         env = self.env = build_env(E, V, M, device, seed=0, env_offset=start)
         # BCD every step: theta lives as the sweep's candidate indices between sweeps (VecEnviron.lazy_theta: the sweep
         # does not write the complex64 tensor, the fused step expands the indices; same outputs bit for bit)
-        env.lazy_theta = mode == "bcd" and not os.environ.get("RISVEC_BENCH_EAGER_THETA")
+        # (not with --steer: that kernel reads the complex64 tensor, which would then be rebuilt from the indices every step)
+        env.lazy_theta = mode == "bcd" and not getattr(opts, "steer", False) and not os.environ.get("RISVEC_BENCH_EAGER_THETA")
         rng = np.random.default_rng(1234 + rank)
         action = torch.from_numpy(rng.uniform(0, 1, (E, 2, V)).astype(np.float32)).to(device)
         partner_np, ng_np = synthetic_groups(E, V, rng)

@@ -49,9 +49,10 @@ __device__ __forceinline__ float4 lat_ld(const float4* p) {
 // STAMP: diagnostic build only (RISVEC_DIAG, tools/lat_stamps.py): TJ.reward is a debug buffer that receives, per
 // wavefront, the s_memrealtime (100 MHz) of: entry, all loads issued, cascade reduced (loads returned), step() done,
 // stores drained.
-template <class S, int EPWT, bool MULTI, bool STAMP = false, bool NT = false, bool TK = false>
+template <class S, int EPWT, bool MULTI, bool STAMP = false, int POL = 0, bool TK = false>
 __global__ void __launch_bounds__(kBlock)
 k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ) {
+    constexpr bool NT = POL == 1, ALT = POL == 2;       // cache policy of the h_r / theta loads: default, non-temporal, default + alternating walk
     constexpr int V = S::V, VP = S::VP, G = S::G, NIT = S::NIT, VPP = S::VPP;
     constexpr int PC = S::PC, CHUNKS = S::CHUNKS, K = S::K;
     constexpr int NU = EPWT * CHUNKS;                          // load units of the wavefront's envs
@@ -63,7 +64,9 @@ k_step_fused_lat(Dims d, RisVecParams P, StepArgs A, int n_steps, RisVecTraj TJ)
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int gl = lane % G, gv = lane / G;
     int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
-    if constexpr (!MULTI) {
+    if constexpr (ALT) {
+        // (its own instantiation: as a run-time flag of every kernel of the family the two scalar instructions and the
+        // argument they wait for cost the 8 192-env shard 8 %: 7.1 -> 7.8 us, bisected in round 3)
         // A stream a little larger than the Infinity Cache (1 ... 1.29 x) is read with the default cache policy and walked
         // in ALTERNATING directions from step to step (A.ping: the launcher's step parity): the lines the previous
         // launch touched last -- the ones still cached -- are the first this launch asks for, where a same-direction
@@ -271,17 +274,18 @@ static bool alternate_walk(const RisVecState& s) {
     return b > tuning().ic_bytes && b <= tuning().lat_nt_from;
 }
 
-template <class S, int EPWT, bool MULTI, bool NT, bool TK>
+// POL: 0 default cache policy, 1 non-temporal loads, 2 default policy + alternating walk (single-step kernels only)
+template <class S, int EPWT, bool MULTI, int POL, bool TK>
 static hipError_t launch_one(const RisVecState& s, const RisVecParams& p, const StepArgs& a0, int n_steps,
                              const RisVecTraj& tj, hipStream_t st) {
+    static_assert(POL != 2 || !MULTI, "the alternating walk is a single-step form");
     const long long waves = ((long long)s.n_envs + EPWT - 1) / EPWT;
     const unsigned grid = (unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave));
     StepArgs a = a0;
-    const bool alt = !MULTI && !NT && alternate_walk(s);
-    a.ping = alt ? (int)(a.counter & 1u) : 0;
-    hipLaunchKernelGGL((k_step_fused_lat<S, EPWT, MULTI, false, NT, TK>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a,
+    a.ping = POL == 2 ? (int)(a.counter & 1u) : 0;
+    hipLaunchKernelGGL((k_step_fused_lat<S, EPWT, MULTI, false, POL, TK>), dim3(grid), dim3(kBlock), 0, st, dims_of(s), p, a,
                        n_steps, tj);
-    const char* pol = NT ? ",NT" : (alt ? ",ALT" : "");        // non-temporal loads / default policy + alternating walk
+    const char* pol = POL == 1 ? ",NT" : (POL == 2 ? ",ALT" : "");
     if (S::FIXED)
         note_kernel("k_step_fused_lat<%d,%d,%d%s%s%s>", S::V, S::MC, EPWT, MULTI ? ",MULTI" : "", pol, TK ? ",TK" : "");
     else
@@ -295,21 +299,24 @@ static hipError_t launch_one(const RisVecState& s, const RisVecParams& p, const 
 template <class S, int EMIN, int EMAX, bool HAS_TK>
 static hipError_t launch_single(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int epwt, bool nt,
                                 hipStream_t st) {
-    const RisVecTraj none{nullptr, nullptr, nullptr};
+    const RisVecTraj none{};
+    const bool alt = !nt && alternate_walk(s);                 // (1, 1.29] x the Infinity Cache: the EMAX kernel, walked both ways
     if (a.theta_k) {
         if constexpr (HAS_TK) {
-            if (nt) return launch_one<S, EMAX, false, true, true>(s, p, a, 1, none, st);
-            return launch_one<S, EMAX, false, false, true>(s, p, a, 1, none, st);
+            if (nt) return launch_one<S, EMAX, false, 1, true>(s, p, a, 1, none, st);
+            if (alt) return launch_one<S, EMAX, false, 2, true>(s, p, a, 1, none, st);
+            return launch_one<S, EMAX, false, 0, true>(s, p, a, 1, none, st);
         } else {
             return hipErrorNotSupported;
         }
     }
-    if (nt) return launch_one<S, EMAX, false, true, false>(s, p, a, 1, none, st);
+    if (nt) return launch_one<S, EMAX, false, 1, false>(s, p, a, 1, none, st);
+    if (alt) return launch_one<S, EMAX, false, 2, false>(s, p, a, 1, none, st);
     if (epwt > EMAX) epwt = EMAX;
     if (epwt < EMIN) epwt = EMIN;
-    if constexpr (EMIN <= 1 && EMAX >= 1) { if (epwt == 1) return launch_one<S, 1, false, false, false>(s, p, a, 1, none, st); }
-    if constexpr (EMIN <= 2 && EMAX >= 2) { if (epwt == 2) return launch_one<S, 2, false, false, false>(s, p, a, 1, none, st); }
-    if constexpr (EMIN <= 4 && EMAX >= 4) { if (epwt >= 3) return launch_one<S, 4, false, false, false>(s, p, a, 1, none, st); }
+    if constexpr (EMIN <= 1 && EMAX >= 1) { if (epwt == 1) return launch_one<S, 1, false, 0, false>(s, p, a, 1, none, st); }
+    if constexpr (EMIN <= 2 && EMAX >= 2) { if (epwt == 2) return launch_one<S, 2, false, 0, false>(s, p, a, 1, none, st); }
+    if constexpr (EMIN <= 4 && EMAX >= 4) { if (epwt >= 3) return launch_one<S, 4, false, 0, false>(s, p, a, 1, none, st); }
     return hipErrorNotSupported;
 }
 
@@ -317,12 +324,12 @@ template <class S>
 static hipError_t launch_multi_shape(const RisVecState& s, const RisVecParams& p, const StepArgs& a, int n_steps,
                                      const RisVecTraj& tj, int epwt, hipStream_t st) {
     switch (epwt) {
-        case 1: return launch_one<S, 1, true, false, false>(s, p, a, n_steps, tj, st);
-        case 2: return launch_one<S, 2, true, false, false>(s, p, a, n_steps, tj, st);
-        case 4: return launch_one<S, 4, true, false, false>(s, p, a, n_steps, tj, st);
+        case 1: return launch_one<S, 1, true, 0, false>(s, p, a, n_steps, tj, st);
+        case 2: return launch_one<S, 2, true, 0, false>(s, p, a, n_steps, tj, st);
+        case 4: return launch_one<S, 4, true, 0, false>(s, p, a, n_steps, tj, st);
         case 8:
             // all 64 lanes stepping: only worth its registers where the step loop dominates (the T-step launch)
-            if constexpr (S::EPW >= 8) return launch_one<S, 8, true, false, false>(s, p, a, n_steps, tj, st);
+            if constexpr (S::EPW >= 8) return launch_one<S, 8, true, 0, false>(s, p, a, n_steps, tj, st);
             return hipErrorNotSupported;
         default: return hipErrorNotSupported;
     }
