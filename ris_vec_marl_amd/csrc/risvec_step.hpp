@@ -364,31 +364,65 @@ __device__ __forceinline__ void ring_st4(float* p, float a, float b, float c, fl
     __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
 }
 
-// this agent's slice of its env's replay row (the ring is write-once data: non-temporal stores)
+// This env's replay row (the ring is write-once data: non-temporal stores), written by the VP lanes of the env TOGETHER.
+// A lane owns vehicle v's pieces of the row -- 5 + 5 floats of the two states, VP + 2 of the action, VP of the mask -- at a
+// stride that is not a multiple of 16 bytes, so storing them straight from the lane is 4- and 8-byte stores 20 / 40 bytes
+// apart: 18 store instructions per wavefront, each touching every line of the segment for a fifth of its bytes.  The row
+// pieces go through the env's slice of LDS instead (written as owned, read back as consecutive 16-byte chunks): 10 store
+// instructions, each a whole run of the row.  32 768 x 8: rollout step with the ring 41.6 -> 39.2 us (the same bytes
+// written perfectly coalesced as a test gave the same 39.2: profiles/r03aw_ring_coalesced_ab.txt).  Same-wave LDS
+// accesses execute in order and an env's lanes touch nothing but its slice: no barrier.
 template <int VP>
 __device__ __forceinline__ void ring_store(const StepArgs& A, int e, int v, const RingIn<VP>& R, const StepIn& in, float Bn,
                                            float data_t, float data_p, float rate, float rew) {
+    static_assert(VP % 4 == 0, "rows are split into 16-byte chunks per lane");
+    constexpr int SL = VP * (VP + 2);                          // floats of the longest row piece (the action)
+    __shared__ float s_row[kBlock / kWave][(kWave / VP) * SL];
+    float* sl = s_row[threadIdx.x / kWave] + ((threadIdx.x % kWave) / VP) * SL;   // this env's slice
     const StepRing& G = A.ring;
     long long row = G.head + e;
     row = row >= G.mem_size ? row - G.mem_size : row;
-    float* s0 = G.state_memory + row * (5 * VP) + v * 5;
-    float* s1 = G.new_state_memory + row * (5 * VP) + v * 5;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) ring_st(s0 + k, R.so[k]);
-    ring_st(s1 + 0, Bn * 0.1f); ring_st(s1 + 1, data_t * 0.1f); ring_st(s1 + 2, data_p * 0.1f); ring_st(s1 + 3, 0.f);
-    ring_st(s1 + 4, rate * 0.05f);
+    // a row piece of 4 VP + VP floats (a state): 16 bytes + 4 bytes per lane
+    const auto put_state = [&](float* dst, float x0, float x1, float x2, float x3, float x4) {
+        float* mine = sl + 5 * v;
+        mine[0] = x0; mine[1] = x1; mine[2] = x2; mine[3] = x3; mine[4] = x4;
+        const float4 q = *reinterpret_cast<const float4*>(sl + 4 * v);
+        const float tail = sl[4 * VP + v];
+        ring_st4(dst + 4 * v, q.x, q.y, q.z, q.w);
+        ring_st(dst + 4 * VP + v, tail);
+    };
+    put_state(G.state_memory + row * (5 * VP), R.so[0], R.so[1], R.so[2], R.so[3], R.so[4]);
+    put_state(G.new_state_memory + row * (5 * VP), Bn * 0.1f, data_t * 0.1f, data_p * 0.1f, 0.f, rate * 0.05f);
     ring_st(G.reward_local_memory + row * VP + v, rew);
-    float* a = G.action_memory + row * (VP * (VP + 2)) + v * (VP + 2);       // 8-byte aligned: VP + 2 is even
+    {   // action: VP (VP + 2) floats = VP/4 runs of 4 VP + one of 2 VP
+        float2* mine = reinterpret_cast<float2*>(sl + (VP + 2) * v);           // 8-byte aligned: VP + 2 is even
 #pragma unroll
-    for (int k = 0; k < VP; k += 2) ring_st2(a + k, k == v ? 0.f : R.prow[k], k + 1 == v ? 0.f : R.prow[k + 1]);
-    ring_st2(a + VP, in.a0, in.a1);                                            // the raw policy output (TRAIN:1777-1782)
-    float* m = G.mask_memory + row * (VP * VP) + v * VP;
-    const bool ones = G.mask == nullptr;
+        for (int k = 0; k < VP; k += 2) mine[k / 2] = make_float2(k == v ? 0.f : R.prow[k], k + 1 == v ? 0.f : R.prow[k + 1]);
+        mine[VP / 2] = make_float2(in.a0, in.a1);                              // the raw policy output (TRAIN:1777-1782)
+        float* a = G.action_memory + row * (VP * (VP + 2));
 #pragma unroll
-    for (int k = 0; k < VP / 4; ++k) {
-        const unsigned w = R.mk[k];
-        ring_st4(m + 4 * k, (ones || (w & 0xFFu)) ? 1.f : 0.f, (ones || (w & 0xFF00u)) ? 1.f : 0.f,
-                 (ones || (w & 0xFF0000u)) ? 1.f : 0.f, (ones || (w & 0xFF000000u)) ? 1.f : 0.f);
+        for (int p = 0; p < VP / 4; ++p) {
+            const float4 q = *reinterpret_cast<const float4*>(sl + p * 4 * VP + 4 * v);
+            ring_st4(a + p * 4 * VP + 4 * v, q.x, q.y, q.z, q.w);
+        }
+        const float2 t2 = *reinterpret_cast<const float2*>(sl + VP * VP + 2 * v);
+        ring_st2(a + VP * VP + 2 * v, t2.x, t2.y);
+    }
+    {   // mask: VP VP floats = VP/4 runs of 4 VP
+        const bool ones = G.mask == nullptr;
+        float4* mine = reinterpret_cast<float4*>(sl + VP * v);
+#pragma unroll
+        for (int k = 0; k < VP / 4; ++k) {
+            const unsigned w = R.mk[k];
+            mine[k] = make_float4((ones || (w & 0xFFu)) ? 1.f : 0.f, (ones || (w & 0xFF00u)) ? 1.f : 0.f,
+                                  (ones || (w & 0xFF0000u)) ? 1.f : 0.f, (ones || (w & 0xFF000000u)) ? 1.f : 0.f);
+        }
+        float* m = G.mask_memory + row * (VP * VP);
+#pragma unroll
+        for (int p = 0; p < VP / 4; ++p) {
+            const float4 q = *reinterpret_cast<const float4*>(sl + p * 4 * VP + 4 * v);
+            ring_st4(m + p * 4 * VP + 4 * v, q.x, q.y, q.z, q.w);
+        }
     }
     if (v == 0) G.terminal_memory[row] = (uint8_t)(G.done ? 1 : 0);
 }
