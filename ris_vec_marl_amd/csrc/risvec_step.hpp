@@ -596,23 +596,9 @@ __device__ __forceinline__ StepCarry step_tail(const Dims& d, const RisVecParams
         st_out(A.over_power + idx, over_power);
         if (A.flags & RISVEC_STEP_OBS) {
             // marl_train_bcd.py:819-827 (element 3 = over_data/10 is always 0)
-            if ((VP == 4 || VP == 8 || VP == 16) && V == VP) {
-                // the env's 5 V floats leave as one 16-byte-per-lane run + one 4-byte-per-lane run (through the env's slice
-                // of LDS, as the ring store does) instead of five 4-byte stores 20 bytes apart
-                __shared__ float s_obs[kBlock / kWave][(kWave / VP) * 5 * VP];
-                float* sl = s_obs[(threadIdx.x / kWave) % (kBlock / kWave)] + ((threadIdx.x % kWave) / VP) * (5 * VP);
-                float* mine = sl + 5 * v;
-                mine[0] = Bn * 0.1f; mine[1] = data_t * 0.1f; mine[2] = data_p * 0.1f; mine[3] = 0.f; mine[4] = rate * 0.05f;
-                const float4 q = *reinterpret_cast<const float4*>(sl + 4 * v);
-                const float tail = sl[4 * VP + v];
-                float* o = A.obs + (long long)e * (5 * VP);
-                *reinterpret_cast<float4*>(o + 4 * v) = q;
-                st_out(o + 4 * VP + v, tail);
-            } else {
-                float* o = A.obs + idx * 5;
-                st_out(o + 0, Bn * 0.1f); st_out(o + 1, data_t * 0.1f); st_out(o + 2, data_p * 0.1f); st_out(o + 3, 0.f);
-                st_out(o + 4, rate * 0.05f);
-            }
+            float* o = A.obs + idx * 5;
+            st_out(o + 0, Bn * 0.1f); st_out(o + 1, data_t * 0.1f); st_out(o + 2, data_p * 0.1f); st_out(o + 3, 0.f);
+            st_out(o + 4, rate * 0.05f);
         }
         if (A.flags & RISVEC_STEP_POWER_W) {
             const float inv_tf = __builtin_amdgcn_rcpf(tf);
