@@ -355,7 +355,7 @@ class Case:
             replay = VecReplayBuffer(16 * E, 5, V + 2, V, device=device)
             # Default (round 3): the transition store rides in the step kernel (risvec_step_ring) where that form exists;
             # RISVEC_BENCH_SEPARATE_STORE=1 keeps the two-launch form (step, then k_replay_store) for A/Bs.
-            self.ring_fused = (direct and not opts.steer and not opts.meter and V in (4, 8, 16) and mode in ("fused", "cached")
+            self.ring_fused = (direct and not opts.steer and V in (4, 8, 16) and mode in ("fused", "cached")
                                and not os.environ.get("RISVEC_BENCH_SEPARATE_STORE")
                                and (mode == "cached" or (V, M) in ((8, 64), (8, 36), (8, 40), (4, 16), (16, 64), (16, 256))))
             if not self.ring_fused:
@@ -383,7 +383,8 @@ class Case:
             launch = env.bind_step_many(actions, partner, n_groups, None, metrics=full, obs=full, out=traj, fused=fused)
             self.multi = T
         elif self.ring_fused:
-            both = env.bind_step_store(replay, power_raw, partner, n_groups, probs, grouper.mask, None, fused=fused, metrics=full)
+            both = env.bind_step_store(replay, power_raw, partner, n_groups, probs, grouper.mask, None, fused=fused, metrics=full,
+                                       power_w=opts.meter)
             self.step_store = both
             launch = lambda: both(False, False)              # noqa: E731  (the untimed naming launch of run())
         else:
